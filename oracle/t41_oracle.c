@@ -1,0 +1,818 @@
+/*
+ * oracle/t41_oracle.c -- CPU restatement of ProcessIQData() and the CMSIS-DSP f32 primitives it
+ * calls.  TEST INFRASTRUCTURE ONLY (see t41_oracle.h): never linked into the product.
+ * PARITY UNPINNED (no reference tests/golden vectors exist; CMSIS-DSP is absent).
+ *
+ * Citations are relative to /root/reference/software/T41_SDR/.
+ * Build: gcc -O2 -std=c11 -ffp-contract=off -fPIC -shared (oracle/Makefile).
+ *
+ * Numeric conventions restated here:
+ *  - every expression keeps the reference's C++ operand types, so float*double promotes to
+ *    double exactly where the reference's does (unsuffixed literals are double: Teensy 4.x
+ *    builds do not use -fsingle-precision-constant);
+ *  - FIR/biquad accumulations are separate multiply and add roundings in tap order (the
+ *    documented scalar CMSIS loops);
+ *  - arm_cfft_f32 is restated as "unscaled forward DFT, natural order; inverse = conjugate,
+ *    forward, conjugate, times 1/N" with f32 twiddles.  CMSIS uses a radix-8 decomposition
+ *    for N=512/4096; this file uses radix-2, so only the rounding pattern (~1e-7 relative)
+ *    can differ from a real CMSIS build.
+ */
+#define _GNU_SOURCE
+#include "t41_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* FIR.h:10-16: the reference redefines these as *float* constants */
+#define PI_F 3.1415926535897932384626433832795f
+#define HALF_PI_F 1.5707963267948966192313216916398f
+#define TWO_PI_F 6.283185307179586476925286766559f
+#define TPI_F TWO_PI_F
+#define PIH_F HALF_PI_F
+#define FOURPI_F (2.0f * TPI_F)
+#define SIXPI_F (3.0f * TPI_F)
+
+#define SAMPLE_RATE 192000 /* T41_SDR.ino:129 */
+static const float DF1 = 4.0f;  /* T41_SDR.ino:333 */
+static const float DF2 = 2.0f;  /* T41_SDR.ino:334 */
+static const float DF = 8.0f;   /* T41_SDR.ino:335 (DF1*DF2) */
+static const float N_ATT = 90.0f; /* T41_SDR.ino:336 */
+
+void t41o_default_params(t41o_params *p) {
+  memset(p, 0, sizeof(*p));
+  p->fft_length = 512;            /* SDT.h:39 */
+  p->mode = T41O_DEMOD_USB;       /* bands[] 20M row, T41_SDR.ino:163 */
+  p->FLoCut = 200;
+  p->FHiCut = 3000;
+  p->rfGainAllBands = 1;          /* gwv.cpp:17 */
+  p->RFgain = 1;                  /* bands[].RFgain */
+  p->IQAmpCorrectionFactor = 1.0f;   /* gwv.cpp:71 */
+  p->IQPhaseCorrectionFactor = 0.0f; /* gwv.cpp:72 */
+  p->AGCMode = 0;                 /* fixed gain */
+  p->audioVolume = 30;            /* gwv.cpp:16 */
+  p->nfmFilterBW = 12000;         /* Filter.cpp:16 */
+  p->xmtMode = T41O_SSB_MODE;     /* gwv.cpp:22 */
+  p->CWFreqShift = 750;
+  p->am_lpf_f0 = 3000;            /* boot band 40M LSB -200/-3000, T41_SDR.ino:560-563 */
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Coefficient design
+ * ---------------------------------------------------------------------------------------- */
+
+/* Utility.cpp:211-229 */
+float t41o_Izero(float x) {
+  float x2 = x / 2.0;
+  float summe = 1.0;
+  float ds = 1.0;
+  float di = 1.0;
+  float errorlimit = 1e-9;
+  float tmp;
+  do {
+    tmp = x2 / di;
+    tmp *= tmp;
+    ds *= tmp;
+    summe += ds;
+    di += 1.0;
+  } while (ds >= errorlimit * summe);
+  return summe;
+}
+
+/* Utility.cpp:197-203 */
+float t41o_MSinc(int m, float fc) {
+  float x = m * PIH_F;
+  if (m == 0) return 1.0f;
+  return sinf(x * fc) / (fc * x);
+}
+
+/* FIR.cpp:908-980.  Types 0 (LP), 1 (HP), 2/3 (BP/notch); the path only uses type 0. */
+void t41o_CalcFIRCoeffs(float *coeffs, int numCoeffs, float fc, float Astop, int type, float dfc,
+                        float Fsamprate) {
+  int nc = numCoeffs;
+  float Beta;
+  float izb;
+  float fcf = fc;
+  float x, w;
+  fc = fc / Fsamprate;
+  dfc = dfc / Fsamprate;
+
+  if (Astop < 20.96) {
+    Beta = 0.0;
+  } else if (Astop >= 50.0) {
+    Beta = 0.1102 * (Astop - 8.71);
+  } else {
+    Beta = 0.5842 * powf((Astop - 20.96), 0.4) + 0.07886 * (Astop - 20.96);
+  }
+  izb = t41o_Izero(Beta);
+  if (type == 0) {
+    fcf = fc * 2.0;
+    nc = numCoeffs;
+  } else if (type == 1) {
+    fcf = -fc;
+    nc = 2 * (numCoeffs / 2);
+  } else {
+    fcf = dfc;
+    nc = 2 * (numCoeffs / 2);
+  }
+  /* FIR.cpp:963-967: ii = -nc, -nc+2, ..., nc-2  ->  nc taps of a (nc+1)-long symmetric
+   * design whose last tap is never written */
+  for (int ii = -nc, jj = 0; ii < nc; ii += 2, jj++) {
+    x = (float)ii / (float)nc;
+    w = t41o_Izero(Beta * sqrtf(1.0f - x * x)) / izb;
+    coeffs[jj] = fcf * t41o_MSinc(ii, fcf) * w;
+  }
+  if (type == 1) {
+    coeffs[nc / 2] += 1;
+  } else if (type == 2) {
+    for (int jj = 0; jj < nc + 1; jj++) coeffs[jj] *= 2.0f * cosf(PIH_F * (2 * jj - nc) * fc);
+  } else if (type == 3) {
+    for (int jj = 0; jj < nc + 1; jj++) coeffs[jj] *= -2.0f * cosf(PIH_F * (2 * jj - nc) * fc);
+    coeffs[nc / 2] += 1;
+  }
+}
+
+/* FIR.cpp:1008-1065 with FIR_filter_window == 1 (FIR.cpp:10): 4-term Blackman-Harris */
+void t41o_CalcCplxFIRCoeffs(float *cI, float *cQ, int numCoeffs, float FLoCut, float FHiCut,
+                            float SampleRate) {
+  float nFL = FLoCut / SampleRate;
+  float nFH = FHiCut / SampleRate;
+  float nFc = (nFH - nFL) / 2.0;
+  float nFs = PI_F * (nFH + nFL);
+  float fCenter = 0.5 * (float)(numCoeffs - 1);
+  float x, z;
+  for (int i = 0; i < numCoeffs; i++) {
+    x = (float)i - fCenter;
+    float ax = (float)i - fCenter;
+    if (ax < 0) ax = -ax;
+    if (ax < 0.01) {
+      z = 2.0 * nFc;
+    } else {
+      z = (float)sinf(TWO_PI_F * x * nFc) / (PI_F * x) *
+          (0.35875 - 0.48829 * cosf((TWO_PI_F * i) / (numCoeffs - 1)) +
+           0.14128 * cosf((FOURPI_F * i) / (numCoeffs - 1)) -
+           0.01168 * cosf((SIXPI_F * i) / (numCoeffs - 1)));
+    }
+    cI[i] = z * cosf(nFs * x);
+    cQ[i] = z * sinf(nFs * x);
+  }
+}
+
+/* FIR.cpp:1076-1116, filter_type 0 (low-pass) and 3 (notch) */
+void t41o_SetIIRCoeffs(float cs[5], float f0, float Q, float sample_rate, int filter_type) {
+  if (f0 > sample_rate / 2.0) f0 = sample_rate / 2.0;
+  float w0 = f0 * (TPI_F / sample_rate);
+  float sinW0 = sinf(w0);
+  float alpha = sinW0 / (Q * 2.0);
+  float cosW0 = cosf(w0);
+  float scale = 1.0 / (1.0 + alpha);
+  if (filter_type == 0) {
+    cs[0] = ((1.0 - cosW0) / 2.0) * scale;
+    cs[1] = (1.0 - cosW0) * scale;
+    cs[2] = cs[0];
+    cs[3] = (2.0 * cosW0) * scale;
+    cs[4] = (-1.0 + alpha) * scale;
+  } else if (filter_type == 3) {
+    cs[0] = 1.0;
+    cs[1] = -2.0 * cosW0;
+    cs[2] = 1.0;
+    cs[3] = 2.0 * cosW0 * scale;
+    cs[4] = alpha - 1.0;
+  }
+}
+
+static int valid_fft_length(int n) { return n == 512 || n == 1024 || n == 2048 || n == 4096; }
+
+/* CalcFilters() Filter.cpp:235-249 -> CalcCplxFIRCoeffs + InitFilterMask (Filter.cpp:260-284)
+ * + SetDecIntFilters (Filter.cpp:396-417); NFM re-designs dec1/dec2 every block
+ * (Process.cpp:259 -> Filter.cpp:429-438). */
+int t41o_design(const t41o_params *p, t41o_coeffs *c) {
+  const int N = p->fft_length;
+  if (!valid_fft_length(N)) return -1;
+  memset(c, 0, sizeof(*c));
+  const int m_NumTaps = N / 2 + 1; /* Filter.cpp:18 */
+  float *cI = (float *)calloc((size_t)m_NumTaps, sizeof(float));
+  float *cQ = (float *)calloc((size_t)m_NumTaps, sizeof(float));
+  t41o_CalcCplxFIRCoeffs(cI, cQ, m_NumTaps, (float)p->FLoCut, (float)p->FHiCut,
+                         (float)SAMPLE_RATE / DF);
+  for (int i = 0; i < m_NumTaps; i++) { /* Filter.cpp:269-274 */
+    c->mask[i * 2] = cI[i];
+    c->mask[i * 2 + 1] = cQ[i];
+  }
+  for (int i = N + 1; i < N * 2; i++) c->mask[i] = 0.0; /* Filter.cpp:276-278: wipes cQ[N/2] */
+  t41o_cfft_f32(c->mask, N, 0);                          /* Filter.cpp:282 */
+  free(cI);
+  free(cQ);
+
+  /* AM low-pass: designed once at boot for the boot band, never redesigned
+   * (T41_SDR.ino:560-566, Filter.cpp:242-244) */
+  t41o_SetIIRCoeffs(c->biquad_lowpass1, (float)p->am_lpf_f0, 1.3, (float)SAMPLE_RATE / DF, 0);
+
+  int filter_BW_highest = p->FHiCut; /* Filter.cpp:400-410 */
+  if (filter_BW_highest < -p->FLoCut) filter_BW_highest = -p->FLoCut;
+  int LP_F_help = filter_BW_highest;
+  if (LP_F_help > 10000) LP_F_help = 10000;
+  t41o_CalcFIRCoeffs(c->dec1, T41O_N_DEC1_TAPS, (float)LP_F_help, N_ATT, 0, 0.0,
+                     (float)SAMPLE_RATE);
+  t41o_CalcFIRCoeffs(c->dec2, T41O_N_DEC2_TAPS, (float)LP_F_help, N_ATT, 0, 0.0,
+                     (float)(SAMPLE_RATE / DF1));
+  t41o_CalcFIRCoeffs(c->int1, T41O_N_INT1_TAPS, (float)LP_F_help, N_ATT, 0, 0.0,
+                     (float)(SAMPLE_RATE / DF1));
+  t41o_CalcFIRCoeffs(c->int2, T41O_N_INT2_TAPS, (float)LP_F_help, N_ATT, 0, 0.0,
+                     (float)SAMPLE_RATE);
+  if (p->mode == T41O_DEMOD_NFM) { /* Filter.cpp:429-438: no 10 kHz cap here */
+    int bw = p->nfmFilterBW;
+    t41o_CalcFIRCoeffs(c->dec1, T41O_N_DEC1_TAPS, (float)bw, N_ATT, 0, 0.0, (float)SAMPLE_RATE);
+    t41o_CalcFIRCoeffs(c->dec2, T41O_N_DEC2_TAPS, (float)bw, N_ATT, 0, 0.0,
+                       (float)(SAMPLE_RATE / DF1));
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * CMSIS-DSP f32 primitives
+ * ---------------------------------------------------------------------------------------- */
+
+/* f32 twiddle tables (cos, sin of 2*pi*k/n for k < n/2), the analogue of CMSIS' twiddleCoef_N
+ * constant tables: computed in double, rounded once to f32.  Built once per size. */
+static float *g_tw[13];
+static pthread_mutex_t g_tw_lock = PTHREAD_MUTEX_INITIALIZER;
+
+static const float *twiddles_for(int n, int logn) {
+  float *tw = __atomic_load_n(&g_tw[logn], __ATOMIC_ACQUIRE);
+  if (tw) return tw;
+  pthread_mutex_lock(&g_tw_lock);
+  tw = g_tw[logn];
+  if (!tw) {
+    tw = (float *)malloc(sizeof(float) * (size_t)n);
+    for (int k = 0; k < n / 2; k++) {
+      double a = 2.0 * 3.14159265358979323846 * (double)k / (double)n;
+      tw[2 * k] = (float)cos(a);
+      tw[2 * k + 1] = (float)sin(a);
+    }
+    __atomic_store_n(&g_tw[logn], tw, __ATOMIC_RELEASE);
+  }
+  pthread_mutex_unlock(&g_tw_lock);
+  return tw;
+}
+
+/* arm_cfft_f32(S, buf, ifftFlag, bitReverseFlag=1): in-place, interleaved re/im. */
+void t41o_cfft_f32(float *buf, int n, int ifft) {
+  int logn = 0;
+  while ((1 << logn) < n) logn++;
+  if (logn > 12 || (1 << logn) != n) return;
+  const float *tw = twiddles_for(n, logn);
+  if (ifft) /* CMSIS: conjugate input */
+    for (int i = 0; i < n; i++) buf[2 * i + 1] = -buf[2 * i + 1];
+  /* bit reversal, then radix-2 decimation-in-time */
+  for (int i = 0, j = 0; i < n; i++) {
+    if (i < j) {
+      float tr = buf[2 * i], ti = buf[2 * i + 1];
+      buf[2 * i] = buf[2 * j];
+      buf[2 * i + 1] = buf[2 * j + 1];
+      buf[2 * j] = tr;
+      buf[2 * j + 1] = ti;
+    }
+    int bit = n >> 1;
+    while (bit && (j & bit)) {
+      j ^= bit;
+      bit >>= 1;
+    }
+    j |= bit;
+  }
+  for (int len = 2; len <= n; len <<= 1) {
+    int half = len >> 1;
+    int step = n / len;
+    for (int base = 0; base < n; base += len) {
+      for (int k = 0; k < half; k++) {
+        float wr = tw[2 * (k * step)];
+        float wi = -tw[2 * (k * step) + 1]; /* e^{-j a} */
+        int a = base + k, b = base + k + half;
+        float xr = buf[2 * b], xi = buf[2 * b + 1];
+        float tr = xr * wr - xi * wi;
+        float ti = xr * wi + xi * wr;
+        float ur = buf[2 * a], ui = buf[2 * a + 1];
+        buf[2 * a] = ur + tr;
+        buf[2 * a + 1] = ui + ti;
+        buf[2 * b] = ur - tr;
+        buf[2 * b + 1] = ui - ti;
+      }
+    }
+  }
+  if (ifft) { /* CMSIS: conjugate and scale by 1/fftLen */
+    float inv = 1.0f / (float)n;
+    for (int i = 0; i < n; i++) {
+      buf[2 * i] = buf[2 * i] * inv;
+      buf[2 * i + 1] = -buf[2 * i + 1] * inv;
+    }
+  }
+}
+
+/* arm_fir_decimate_f32: state = [numTaps-1 history | blockSize new]; output n =
+ * sum_i pCoeffs[i]*state[n*M+i] accumulated in tap order from 0; history = last numTaps-1. */
+void t41o_fir_decimate_f32(const float *coeffs, int ntaps, int M, float *state, const float *src,
+                           float *dst, int blockSize) {
+  const int nout = blockSize / M;
+  float *cur = state + (ntaps - 1);
+  for (int i = 0; i < blockSize; i++) cur[i] = src[i]; /* src may alias dst: copied first */
+  for (int n = 0; n < nout; n++) {
+    const float *px = state + n * M;
+    float acc = 0.0f;
+    for (int i = 0; i < ntaps; i++) acc += px[i] * coeffs[i];
+    dst[n] = acc;
+  }
+  memmove(state, state + nout * M, sizeof(float) * (size_t)(ntaps - 1));
+}
+
+/* arm_fir_interpolate_f32: phaseLength P = numTaps/L; state = [P-1 history | new]; for input
+ * n and j = 1..L: out[n*L+j-1] = sum_t state[n+t]*pCoeffs[(L-j)+t*L]. */
+void t41o_fir_interpolate_f32(const float *coeffs, int ntaps, int L, float *state,
+                              const float *src, float *dst, int blockSize) {
+  const int P = ntaps / L;
+  float *cur = state + (P - 1);
+  for (int i = 0; i < blockSize; i++) cur[i] = src[i];
+  for (int n = 0; n < blockSize; n++) {
+    for (int j = 1; j <= L; j++) {
+      float acc = 0.0f;
+      const float *px = state + n;
+      const float *pc = coeffs + (L - j);
+      for (int t = 0; t < P; t++) {
+        acc += px[t] * pc[t * L];
+      }
+      dst[n * L + (j - 1)] = acc;
+    }
+  }
+  memmove(state, state + blockSize, sizeof(float) * (size_t)(P - 1));
+}
+
+/* arm_biquad_cascade_df2T_f32, one stage; coeffs {b0,b1,b2,a1,a2} with a's pre-negated */
+void t41o_biquad_df2T_f32(const float c[5], float st[2], const float *src, float *dst, int n) {
+  float d1 = st[0], d2 = st[1];
+  for (int i = 0; i < n; i++) {
+    float x = src[i];
+    float acc = c[0] * x + d1;
+    d1 = c[1] * x + d2;
+    d1 += c[3] * acc;
+    d2 = c[2] * x;
+    d2 += c[4] * acc;
+    dst[i] = acc;
+  }
+  st[0] = d1;
+  st[1] = d2;
+}
+
+/* arm_biquad_cascade_df1_f32, one stage; state {x[n-1],x[n-2],y[n-1],y[n-2]} */
+void t41o_biquad_df1_f32(const float c[5], float st[4], const float *src, float *dst, int n) {
+  float x1 = st[0], x2 = st[1], y1 = st[2], y2 = st[3];
+  for (int i = 0; i < n; i++) {
+    float x = src[i];
+    float acc = (c[0] * x) + (c[1] * x1) + (c[2] * x2) + (c[3] * y1) + (c[4] * y2);
+    x2 = x1;
+    x1 = x;
+    y2 = y1;
+    y1 = acc;
+    dst[i] = acc;
+  }
+  st[0] = x1;
+  st[1] = x2;
+  st[2] = y1;
+  st[3] = y2;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Channel state
+ * ---------------------------------------------------------------------------------------- */
+struct t41o_channel {
+  int N, D, L;
+  float dc_state[2];              /* HP_DC_Butter_state2, Process.cpp:42 (shared by I and Q) */
+  double Osc_Vect_Q, Osc_Vect_I;  /* Freq_Shift.cpp:13-14 */
+  float *dec1_I_state, *dec1_Q_state; /* T41_SDR.ino:388,393 */
+  float *dec2_I_state, *dec2_Q_state; /* T41_SDR.ino:389-390 */
+  float *int1_state, *int2_state;     /* T41_SDR.ino:394,391 */
+  float *last_L, *last_R;             /* last_sample_buffer_L/R, T41_SDR.ino:403-404 */
+  int first_block;                    /* Process.cpp:47 */
+  float wold;                         /* Process.cpp:73 */
+  float lp1_state[4];                 /* biquad_lowpass1_state, T41_SDR.ino:373 */
+  float nfm_last_i, nfm_last_q;       /* Demod.cpp:221-222 */
+  /* working buffers (the reference's globals) */
+  float *float_buffer_L, *float_buffer_R, *float_buffer_L_EX, *float_buffer_R_EX;
+  float *FFT_buffer, *iFFT_buffer;
+  /* taps */
+  float *tap_ncoI, *tap_ncoQ, *tap_decI, *tap_decQ, *tap_ifft, *tap_demod;
+};
+
+static float *fzalloc(size_t n) { return (float *)calloc(n, sizeof(float)); }
+
+t41o_channel *t41o_channel_create(int fft_length) {
+  if (!valid_fft_length(fft_length)) return NULL;
+  t41o_channel *ch = (t41o_channel *)calloc(1, sizeof(*ch));
+  const int N = fft_length, D = N / 2, L = 4 * N; /* N_BLOCKS*BUFFER_SIZE, T41_SDR.ino:368 */
+  ch->N = N;
+  ch->D = D;
+  ch->L = L;
+  ch->dec1_I_state = fzalloc((size_t)(T41O_N_DEC1_TAPS - 1 + L));
+  ch->dec1_Q_state = fzalloc((size_t)(T41O_N_DEC1_TAPS - 1 + L));
+  ch->dec2_I_state = fzalloc((size_t)(T41O_N_DEC2_TAPS - 1 + L / 4));
+  ch->dec2_Q_state = fzalloc((size_t)(T41O_N_DEC2_TAPS - 1 + L / 4));
+  ch->int1_state = fzalloc((size_t)(24 - 1 + D));
+  ch->int2_state = fzalloc((size_t)(8 - 1 + 2 * D));
+  ch->last_L = fzalloc((size_t)D);
+  ch->last_R = fzalloc((size_t)D);
+  ch->float_buffer_L = fzalloc((size_t)L);
+  ch->float_buffer_R = fzalloc((size_t)L);
+  ch->float_buffer_L_EX = fzalloc((size_t)L);
+  ch->float_buffer_R_EX = fzalloc((size_t)L);
+  ch->FFT_buffer = fzalloc((size_t)(2 * N));
+  ch->iFFT_buffer = fzalloc((size_t)(2 * N + 1));
+  ch->tap_ncoI = fzalloc((size_t)L);
+  ch->tap_ncoQ = fzalloc((size_t)L);
+  ch->tap_decI = fzalloc((size_t)D);
+  ch->tap_decQ = fzalloc((size_t)D);
+  ch->tap_ifft = fzalloc((size_t)(2 * N));
+  ch->tap_demod = fzalloc((size_t)D);
+  t41o_channel_reset(ch);
+  return ch;
+}
+
+void t41o_channel_destroy(t41o_channel *ch) {
+  if (!ch) return;
+  free(ch->dec1_I_state);
+  free(ch->dec1_Q_state);
+  free(ch->dec2_I_state);
+  free(ch->dec2_Q_state);
+  free(ch->int1_state);
+  free(ch->int2_state);
+  free(ch->last_L);
+  free(ch->last_R);
+  free(ch->float_buffer_L);
+  free(ch->float_buffer_R);
+  free(ch->float_buffer_L_EX);
+  free(ch->float_buffer_R_EX);
+  free(ch->FFT_buffer);
+  free(ch->iFFT_buffer);
+  free(ch->tap_ncoI);
+  free(ch->tap_ncoQ);
+  free(ch->tap_decI);
+  free(ch->tap_decQ);
+  free(ch->tap_ifft);
+  free(ch->tap_demod);
+  free(ch);
+}
+
+void t41o_channel_reset(t41o_channel *ch) {
+  const int L = ch->L, D = ch->D;
+  ch->dc_state[0] = ch->dc_state[1] = 0.0f;
+  ch->Osc_Vect_Q = 1.0;
+  ch->Osc_Vect_I = 0.0;
+  memset(ch->dec1_I_state, 0, sizeof(float) * (size_t)(T41O_N_DEC1_TAPS - 1 + L));
+  memset(ch->dec1_Q_state, 0, sizeof(float) * (size_t)(T41O_N_DEC1_TAPS - 1 + L));
+  memset(ch->dec2_I_state, 0, sizeof(float) * (size_t)(T41O_N_DEC2_TAPS - 1 + L / 4));
+  memset(ch->dec2_Q_state, 0, sizeof(float) * (size_t)(T41O_N_DEC2_TAPS - 1 + L / 4));
+  memset(ch->int1_state, 0, sizeof(float) * (size_t)(23 + D));
+  memset(ch->int2_state, 0, sizeof(float) * (size_t)(7 + 2 * D));
+  memset(ch->last_L, 0, sizeof(float) * (size_t)D);
+  memset(ch->last_R, 0, sizeof(float) * (size_t)D);
+  ch->first_block = 1;
+  ch->wold = 0.0f;
+  memset(ch->lp1_state, 0, sizeof(ch->lp1_state));
+  ch->nfm_last_i = ch->nfm_last_q = 0.0f;
+}
+
+int t41o_channel_tap(const t41o_channel *ch, int which, float *dst, int maxlen) {
+  const float *src = NULL;
+  int n = 0;
+  switch (which) {
+    case T41O_TAP_POST_NCO_I: src = ch->tap_ncoI; n = ch->L; break;
+    case T41O_TAP_POST_NCO_Q: src = ch->tap_ncoQ; n = ch->L; break;
+    case T41O_TAP_DEC_I: src = ch->tap_decI; n = ch->D; break;
+    case T41O_TAP_DEC_Q: src = ch->tap_decQ; n = ch->D; break;
+    case T41O_TAP_IFFT: src = ch->tap_ifft; n = 2 * ch->N; break;
+    case T41O_TAP_DEMOD: src = ch->tap_demod; n = ch->D; break;
+    default: return -1;
+  }
+  if (n > maxlen) n = maxlen;
+  memcpy(dst, src, sizeof(float) * (size_t)n);
+  return n;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * The block function
+ * ---------------------------------------------------------------------------------------- */
+
+/* HP_DC_Filter_Coeffs2, FIR.cpp:87-89 */
+static const float HP_DC_Filter_Coeffs2[5] = {
+    0.927176191943378969, -0.927176191943378969, 0.000000000000000000, 0.854352383886757938,
+    0.000000000000000000};
+
+/* Utility.cpp:269-285 */
+static float AlphaBetaMag(float inphase, float quadrature) {
+  const float alpha = 0.960433870103;
+  const float beta = 0.397824734759;
+  float abs_inphase = fabs(inphase);
+  float abs_quadrature = fabs(quadrature);
+  if (abs_inphase > abs_quadrature) return alpha * abs_inphase + beta * abs_quadrature;
+  return alpha * abs_quadrature + beta * abs_inphase;
+}
+
+/* Process.cpp:955-967 */
+static float VolumeToAmplification(int volume) {
+  float x = volume / 100.0f;
+  float ampl = 5 * x * x * x * x * x;
+  return ampl;
+}
+
+#define fmdemod_quadri_K 0.340447550238101026565118445432744920253753662109375 /* Demod.h:7 */
+
+/* Demod.cpp:220-235.  Note the reference saves input[input_size-2], input[input_size-1] as the
+ * "last sample": that is complex sample input_size/2-1, not the last one (faithfully kept). */
+static void nfmdemod(t41o_channel *ch, const float *input, float *output, int input_size) {
+  output[0] = fmdemod_quadri_K *
+              (input[0] * (input[1] - ch->nfm_last_q) - input[1] * (input[0] - ch->nfm_last_i)) /
+              (input[0] * input[0] + input[1] * input[1]);
+  for (int i = 1; i < input_size; i++) {
+    float qnow = input[i * 2 + 1];
+    float qlast = input[(i - 1) * 2 + 1];
+    float inow = input[i * 2];
+    float ilast = input[(i - 1) * 2];
+    output[i] = fmdemod_quadri_K * (qnow * ilast - inow * qlast) / (inow * inow + qnow * qnow);
+  }
+  ch->nfm_last_i = input[input_size - 2];
+  ch->nfm_last_q = input[input_size - 1];
+}
+
+/* DSP_Fn.cpp:494-502 (AGCMode == 0): fixed_gain = 20 (DSP_Fn.cpp:453) on the upper half */
+static void AGC_off(float *iFFT_buffer, int N) {
+  const float fixed_gain = 20.0;
+  for (int i = 0; i < N / 2; i++) {
+    iFFT_buffer[N + 2 * i + 0] = fixed_gain * iFFT_buffer[N + 2 * i + 0];
+    iFFT_buffer[N + 2 * i + 1] = fixed_gain * iFFT_buffer[N + 2 * i + 1];
+  }
+}
+
+static void cmplx_mult_cmplx(const float *a, const float *b, float *d, int n) {
+  for (int i = 0; i < n; i++) { /* arm_cmplx_mult_cmplx_f32 */
+    float ar = a[2 * i], ai = a[2 * i + 1], br = b[2 * i], bi = b[2 * i + 1];
+    d[2 * i] = ar * br - ai * bi;
+    d[2 * i + 1] = ar * bi + ai * br;
+  }
+}
+
+int t41o_process_frame(t41o_channel *ch, const t41o_params *p, const t41o_coeffs *c, long NCOFreq,
+                       const float *I, const float *Q, float *audio) {
+  const int N = ch->N, D = ch->D, L = ch->L;
+  if (p->fft_length != N) return -1;
+  if (p->AGCMode != 0) return -2;
+  const int mode = p->mode;
+  if (mode < T41O_DEMOD_USB || mode > T41O_DEMOD_NFM) return -3;
+  float *fL = ch->float_buffer_L, *fR = ch->float_buffer_R;
+  float *exL = ch->float_buffer_L_EX, *exR = ch->float_buffer_R_EX;
+  float *FFT_buffer = ch->FFT_buffer, *iFFT_buffer = ch->iFFT_buffer;
+
+  /* the f32 I/Q boundary: float_buffer_L = I, float_buffer_R = Q (after Process.cpp:107-108) */
+  memcpy(fL, I, sizeof(float) * (size_t)L);
+  memcpy(fR, Q, sizeof(float) * (size_t)L);
+
+  /* Process.cpp:117-119 */
+  float rfGainValue = pow(10, (float)p->rfGainAllBands / 20);
+  for (int i = 0; i < L; i++) fL[i] = fL[i] * rfGainValue;
+  for (int i = 0; i < L; i++) fR[i] = fR[i] * rfGainValue;
+
+  /* Process.cpp:127-128: one shared instance, L then R (reference hard-codes 2048 = frame_len) */
+  t41o_biquad_df2T_f32(HP_DC_Filter_Coeffs2, ch->dc_state, fL, fL, L);
+  t41o_biquad_df2T_f32(HP_DC_Filter_Coeffs2, ch->dc_state, fR, fR, L);
+
+  /* Process.cpp:133-134 */
+  {
+    float g = (float)p->RFgain;
+    for (int i = 0; i < L; i++) fL[i] = fL[i] * g;
+    for (int i = 0; i < L; i++) fR[i] = fR[i] * g;
+  }
+
+  /* Process.cpp:165-173: USB, LSB, AM (and SAM) only */
+  if (mode == T41O_DEMOD_LSB || mode == T41O_DEMOD_AM || mode == T41O_DEMOD_USB) {
+    float s = -p->IQAmpCorrectionFactor;
+    for (int i = 0; i < L; i++) fL[i] = fL[i] * s;
+    float factor = p->IQPhaseCorrectionFactor; /* Utility.cpp:178-187 */
+    if (factor < 0.0) {
+      for (int i = 0; i < L; i++) fR[i] = fR[i] + fL[i] * factor;
+    } else {
+      for (int i = 0; i < L; i++) fL[i] = fL[i] + fR[i] * factor;
+    }
+  }
+
+  /* FreqShift1, Freq_Shift.cpp:42-65 */
+  for (int i = 0; i < L; i += 4) {
+    float hh1, hh2;
+    hh1 = -fR[i + 1];
+    hh2 = fL[i + 1];
+    fL[i + 1] = hh1;
+    fR[i + 1] = hh2;
+    hh1 = -fL[i + 2];
+    hh2 = -fR[i + 2];
+    fL[i + 2] = hh1;
+    fR[i + 2] = hh2;
+    hh1 = fR[i + 3];
+    hh2 = -fL[i + 3];
+    fL[i + 3] = hh1;
+    fR[i + 3] = hh2;
+  }
+  for (int i = 0; i < L; i++) {
+    exL[i] = fL[i];
+    exR[i] = fR[i];
+  }
+
+  /* FreqShift2, Freq_Shift.cpp:94-141 */
+  {
+    int sideToneShift = 0;
+    if (p->xmtMode == T41O_CW_MODE) {
+      if (mode == 1) sideToneShift = p->CWFreqShift;
+      else if (mode == 0) sideToneShift = -p->CWFreqShift;
+    }
+    float NCO_INC = 2.0 * PI_F * (NCOFreq + sideToneShift) / 192000.0;
+    double OSC_COS = cos(NCO_INC);
+    double OSC_SIN = sin(NCO_INC);
+    double Osc_Vect_Q = ch->Osc_Vect_Q, Osc_Vect_I = ch->Osc_Vect_I;
+    for (int i = 0; i < L; i++) {
+      double Osc_Q = (Osc_Vect_Q * OSC_COS) - (Osc_Vect_I * OSC_SIN);
+      double Osc_I = (Osc_Vect_I * OSC_COS) + (Osc_Vect_Q * OSC_SIN);
+      double Osc_Gain = 1.95 - ((Osc_Vect_Q * Osc_Vect_Q) + (Osc_Vect_I * Osc_Vect_I));
+      Osc_Vect_Q = Osc_Gain * Osc_Q;
+      Osc_Vect_I = Osc_Gain * Osc_I;
+      float freqAdjFactor = 1.1;
+      fL[i] = (exL[i] * freqAdjFactor * Osc_Q) + (exR[i] * freqAdjFactor * Osc_I);
+      fR[i] = (exR[i] * freqAdjFactor * Osc_Q) - (exL[i] * freqAdjFactor * Osc_I);
+    }
+    ch->Osc_Vect_Q = Osc_Vect_Q;
+    ch->Osc_Vect_I = Osc_Vect_I;
+  }
+  memcpy(ch->tap_ncoI, fL, sizeof(float) * (size_t)L);
+  memcpy(ch->tap_ncoQ, fR, sizeof(float) * (size_t)L);
+
+  /* decimation: Process.cpp:262-267 (NFM) / 474-479 (default) */
+  t41o_fir_decimate_f32(c->dec1, T41O_N_DEC1_TAPS, 4, ch->dec1_I_state, fL, fL, L);
+  t41o_fir_decimate_f32(c->dec1, T41O_N_DEC1_TAPS, 4, ch->dec1_Q_state, fR, fR, L);
+  t41o_fir_decimate_f32(c->dec2, T41O_N_DEC2_TAPS, 2, ch->dec2_I_state, fL, fL, L / 4);
+  t41o_fir_decimate_f32(c->dec2, T41O_N_DEC2_TAPS, 2, ch->dec2_Q_state, fR, fR, L / 4);
+
+  if (mode == T41O_DEMOD_NFM) {
+    /* Process.cpp:272-275 */
+    for (int i = 0; i < D; i++) {
+      FFT_buffer[N + i * 2] = fL[i];
+      FFT_buffer[N + i * 2 + 1] = fR[i];
+    }
+    memcpy(ch->tap_decI, fL, sizeof(float) * (size_t)D);
+    memcpy(ch->tap_decQ, fR, sizeof(float) * (size_t)D);
+  } else {
+    /* Process.cpp:481-492 level adjust */
+    float freqKHzFcut;
+    float volScaleFactor;
+    if (mode == T41O_DEMOD_LSB) freqKHzFcut = -(float)p->FLoCut * 0.001;
+    else freqKHzFcut = (float)p->FHiCut * 0.001;
+    volScaleFactor = 7.0874 * pow(freqKHzFcut, -1.232);
+    for (int i = 0; i < D; i++) fL[i] = fL[i] * volScaleFactor;
+    for (int i = 0; i < D; i++) fR[i] = fR[i] * volScaleFactor;
+    memcpy(ch->tap_decI, fL, sizeof(float) * (size_t)D);
+    memcpy(ch->tap_decQ, fR, sizeof(float) * (size_t)D);
+
+    /* Process.cpp:498-522 overlap-save assemble */
+    if (ch->first_block) {
+      for (int i = 0; i < N; i++) FFT_buffer[i] = 0.0;
+      ch->first_block = 0;
+    } else {
+      for (int i = 0; i < D; i++) {
+        FFT_buffer[i * 2] = ch->last_L[i];
+        FFT_buffer[i * 2 + 1] = ch->last_R[i];
+      }
+    }
+    for (int i = 0; i < D; i++) {
+      ch->last_L[i] = fL[i];
+      ch->last_R[i] = fR[i];
+      FFT_buffer[N + i * 2] = fL[i];
+      FFT_buffer[N + i * 2 + 1] = fR[i];
+    }
+    t41o_cfft_f32(FFT_buffer, N, 0);                      /* Process.cpp:535 */
+    cmplx_mult_cmplx(FFT_buffer, c->mask, iFFT_buffer, N); /* Process.cpp:547 */
+    t41o_cfft_f32(iFFT_buffer, N, 1);                     /* Process.cpp:595 */
+    AGC_off(iFFT_buffer, N);                              /* Process.cpp:605 */
+  }
+
+  /* demodulation, Process.cpp:615-761 */
+  switch (mode) {
+    case T41O_DEMOD_USB:
+    case T41O_DEMOD_LSB:
+      for (int i = 0; i < D; i++) {
+        fL[i] = iFFT_buffer[N + (i * 2)];
+        fR[i] = fL[i];
+      }
+      break;
+    case T41O_DEMOD_AM:
+      for (int i = 0; i < D; i++) { /* Process.cpp:698-704 */
+        float audiotmp = AlphaBetaMag(iFFT_buffer[N + (i * 2)], iFFT_buffer[N + (i * 2) + 1]);
+        float w = audiotmp + ch->wold * 0.99f;
+        fL[i] = w - ch->wold;
+        ch->wold = w;
+      }
+      t41o_biquad_df1_f32(c->biquad_lowpass1, ch->lp1_state, fL, fR, D); /* Process.cpp:705 */
+      memcpy(fL, fR, sizeof(float) * (size_t)D);
+      break;
+    case T41O_DEMOD_NFM:
+      nfmdemod(ch, &FFT_buffer[N], fL, D); /* Process.cpp:716 */
+      for (int i = 1; i < D; i++) {        /* Process.cpp:719-727 (starts at 1) */
+        float tmp = fL[i];
+        tmp = (1 < tmp) ? 1 : tmp;
+        tmp = (-1 > tmp) ? -1 : tmp;
+        fL[i] = tmp;
+      }
+      break;
+  }
+
+  if (mode == T41O_DEMOD_NFM) { /* Process.cpp:765-816: real overlap-save through the mask */
+    for (int i = 0; i < D; i++) {
+      FFT_buffer[i * 2] = ch->last_L[i];
+      FFT_buffer[i * 2 + 1] = 0;
+      ch->last_L[i] = fL[i];
+      FFT_buffer[N + i * 2] = fL[i];
+      FFT_buffer[N + i * 2 + 1] = 0;
+    }
+    t41o_cfft_f32(FFT_buffer, N, 0);
+    cmplx_mult_cmplx(FFT_buffer, c->mask, iFFT_buffer, N);
+    t41o_cfft_f32(iFFT_buffer, N, 1);
+    AGC_off(iFFT_buffer, N);
+    for (int i = 0; i < D; i++) fL[i] = iFFT_buffer[N + (i * 2)];
+  }
+  memcpy(ch->tap_ifft, iFFT_buffer, sizeof(float) * (size_t)(2 * N));
+  memcpy(ch->tap_demod, fL, sizeof(float) * (size_t)D);
+
+  /* interpolation, Process.cpp:917-920 (iFFT_buffer is scratch for the x2 stage) */
+  t41o_fir_interpolate_f32(c->int1, T41O_N_INT1_TAPS, 2, ch->int1_state, fL, iFFT_buffer, D);
+  t41o_fir_interpolate_f32(c->int2, T41O_N_INT2_TAPS, 4, ch->int2_state, iFFT_buffer, fL, 2 * D);
+
+  /* Process.cpp:929 */
+  {
+    float s = DF * VolumeToAmplification(p->audioVolume);
+    for (int i = 0; i < L; i++) audio[i] = fL[i] * s;
+  }
+  (void)DF2;
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Batch driver (tests / CPU baseline)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  t41o_channel **chs;
+  int c0, c1, nframes;
+  const t41o_params *p;
+  const t41o_coeffs *c;
+  const int32_t *nco;
+  const float *I, *Q;
+  float *audio;
+  int rc;
+} batch_job;
+
+static void *batch_worker(void *arg) {
+  batch_job *j = (batch_job *)arg;
+  j->rc = 0;
+  for (int ch = j->c0; ch < j->c1; ch++) {
+    const int L = j->chs[ch]->L;
+    const size_t stride = (size_t)j->nframes * (size_t)L;
+    for (int f = 0; f < j->nframes; f++) {
+      size_t off = (size_t)ch * stride + (size_t)f * (size_t)L;
+      int rc = t41o_process_frame(j->chs[ch], j->p, j->c, (long)j->nco[ch], j->I + off, j->Q + off,
+                                  j->audio + off);
+      if (rc) j->rc = rc;
+    }
+  }
+  return NULL;
+}
+
+int t41o_process_batch(t41o_channel **chs, int nchan, int nframes, const t41o_params *p,
+                       const t41o_coeffs *c, const int32_t *NCOFreq, const float *I,
+                       const float *Q, float *audio, int nthreads) {
+  if (nthreads < 1) nthreads = 1;
+  if (nthreads > nchan) nthreads = nchan;
+  if (nthreads > 256) nthreads = 256;
+  batch_job jobs[256];
+  pthread_t th[256];
+  int per = (nchan + nthreads - 1) / nthreads;
+  int used = 0;
+  for (int t = 0; t < nthreads; t++) {
+    int c0 = t * per, c1 = c0 + per;
+    if (c0 >= nchan) break;
+    if (c1 > nchan) c1 = nchan;
+    jobs[t] = (batch_job){chs, c0, c1, nframes, p, c, NCOFreq, I, Q, audio, 0};
+    used++;
+  }
+  if (used == 1) {
+    batch_worker(&jobs[0]);
+    return jobs[0].rc;
+  }
+  for (int t = 0; t < used; t++) pthread_create(&th[t], NULL, batch_worker, &jobs[t]);
+  int rc = 0;
+  for (int t = 0; t < used; t++) {
+    pthread_join(th[t], NULL);
+    if (jobs[t].rc) rc = jobs[t].rc;
+  }
+  return rc;
+}

@@ -1,0 +1,133 @@
+/*
+ * oracle/t41_oracle.h -- CPU restatement of the T41 receive DSP block function.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, the smoke check in
+ * __graft_entry__.py and bench.py's cpu_baseline leg may load it.  The product
+ * (t41_sdr_amd/, include/t41rx.h) never links, imports or calls anything in oracle/.
+ *
+ * PARITY UNPINNED: the reference (tmr4/T41_SDR, /root/reference/software/T41_SDR) ships no
+ * tests, golden vectors or known-answer fixtures for this path, cannot be compiled here
+ * (Arduino/Teensy only) and its arithmetic lives in ARM CMSIS-DSP (arm_math.h, SDT.h:22-23;
+ * version not pinned by the reference), which is neither vendored nor installed.  This file
+ * restates (a) the reference's own C++ for the path and (b) the published scalar algorithms of
+ * the CMSIS-DSP f32 primitives it calls.  It is cross-checked against an independent float64
+ * numpy/scipy model in tests/test_oracle_vs_f64.py.
+ *
+ * All "file:line" citations are relative to /root/reference/software/T41_SDR/.
+ * Plain C (C11), scalar f32 with the reference's float/double promotions; compile with
+ * -ffp-contract=off so that a*b+c is two roundings as in the documented CMSIS scalar loops.
+ */
+#ifndef T41_ORACLE_H
+#define T41_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* demodulation modes, SDT.h:58-68 */
+enum {
+  T41O_DEMOD_USB = 0,
+  T41O_DEMOD_LSB = 1,
+  T41O_DEMOD_AM  = 2,
+  T41O_DEMOD_NFM = 3
+};
+
+/* xmtMode, SDT.h:48-50 */
+enum { T41O_SSB_MODE = 0, T41O_CW_MODE = 1, T41O_DATA_MODE = 2 };
+
+#define T41O_N_DEC1_TAPS 28 /* n_dec1_taps, T41_SDR.ino:344 (evaluates to 28) */
+#define T41O_N_DEC2_TAPS 46 /* n_dec2_taps, T41_SDR.ino:345 (evaluates to 46) */
+#define T41O_N_INT1_TAPS 48 /* T41_SDR.ino:595-603 */
+#define T41O_N_INT2_TAPS 32 /* T41_SDR.ino:608-616 */
+
+/* The globals ProcessIQData() reads, gathered in one POD. */
+typedef struct {
+  int32_t fft_length;       /* FFT_LENGTH SDT.h:39 (512); 1024/2048/4096 = synthetic generalisation */
+  int32_t mode;             /* bands[currentBand].mode */
+  int32_t FLoCut;           /* bands[currentBand].FLoCut, Hz */
+  int32_t FHiCut;           /* bands[currentBand].FHiCut, Hz */
+  int32_t rfGainAllBands;   /* gwv.cpp:17 */
+  int32_t RFgain;           /* bands[currentBand].RFgain (int) */
+  float   IQAmpCorrectionFactor;   /* gwv.cpp:71 */
+  float   IQPhaseCorrectionFactor; /* gwv.cpp:72 */
+  int32_t AGCMode;          /* gwv.cpp:15; only 0 (fixed gain) is restated */
+  int32_t audioVolume;      /* gwv.cpp:16 */
+  int32_t nfmFilterBW;      /* Filter.cpp:16 */
+  int32_t xmtMode;          /* gwv.cpp:22 */
+  int32_t CWFreqShift;      /* Freq_Shift.cpp:113-116 */
+  int32_t am_lpf_f0;        /* cutoff the AM biquad was designed for at boot, T41_SDR.ino:560-566 (3000) */
+} t41o_params;
+
+/* Coefficients CalcFilters()/SetDecIntFilters()/InitFilterMask() produce. */
+typedef struct {
+  float dec1[T41O_N_DEC1_TAPS];
+  float dec2[T41O_N_DEC2_TAPS];
+  float int1[T41O_N_INT1_TAPS];
+  float int2[T41O_N_INT2_TAPS];
+  float biquad_lowpass1[5];
+  float mask[2 * 4096];     /* FIR_filter_mask, 2*fft_length floats used */
+} t41o_coeffs;
+
+typedef struct t41o_channel t41o_channel; /* per-channel persistent state, opaque */
+
+void t41o_default_params(t41o_params *p);
+
+/* ---- coefficient design (FIR.cpp / Filter.cpp / Utility.cpp restatements) ---- */
+float t41o_Izero(float x);
+float t41o_MSinc(int m, float fc);
+void  t41o_CalcFIRCoeffs(float *coeffs, int numCoeffs, float fc, float Astop, int type, float dfc,
+                         float Fsamprate);
+void  t41o_CalcCplxFIRCoeffs(float *cI, float *cQ, int numCoeffs, float FLoCut, float FHiCut,
+                             float SampleRate);
+void  t41o_SetIIRCoeffs(float coefficient_set[5], float f0, float Q, float sample_rate,
+                        int filter_type);
+/* full designer: what CalcFilters() (+ per-block SetDecIntFilters(nfmFilterBW) in NFM) leaves in
+ * the coefficient arrays for these params */
+int   t41o_design(const t41o_params *p, t41o_coeffs *c);
+
+/* ---- CMSIS-DSP f32 primitive restatements ---- */
+void t41o_cfft_f32(float *buf, int n, int ifft);                       /* arm_cfft_f32(S,buf,ifft,1) */
+void t41o_fir_decimate_f32(const float *coeffs, int ntaps, int M, float *state,
+                           const float *src, float *dst, int blockSize);
+void t41o_fir_interpolate_f32(const float *coeffs, int ntaps, int L, float *state,
+                              const float *src, float *dst, int blockSize);
+void t41o_biquad_df2T_f32(const float coeffs[5], float state[2], const float *src, float *dst,
+                          int n);
+void t41o_biquad_df1_f32(const float coeffs[5], float state[4], const float *src, float *dst,
+                         int n);
+
+/* ---- channel state + the block function ---- */
+t41o_channel *t41o_channel_create(int fft_length);
+void t41o_channel_destroy(t41o_channel *ch);
+void t41o_channel_reset(t41o_channel *ch); /* power-on values (Osc_Vect_Q = 1, first_block = 1) */
+
+/* One ProcessIQData() call (Process.cpp:70-944) for one channel:
+ * I,Q: frame_len = 4*fft_length planar f32 samples in, audio: frame_len f32 samples out. */
+int t41o_process_frame(t41o_channel *ch, const t41o_params *p, const t41o_coeffs *c,
+                       long NCOFreq, const float *I, const float *Q, float *audio);
+
+/* Batched convenience for tests/bench: channels are independent; runs nframes consecutive
+ * frames of each channel.  Layout: I,Q,audio are [nchan][nframes*frame_len].
+ * nthreads <= 1 runs serially. */
+int t41o_process_batch(t41o_channel **chs, int nchan, int nframes, const t41o_params *p,
+                       const t41o_coeffs *c, const int32_t *NCOFreq, const float *I,
+                       const float *Q, float *audio, int nthreads);
+
+/* debugging taps for stage-level parity tests: copies of intermediate buffers of the
+ * last processed frame (lengths in floats); returns number of floats written */
+enum {
+  T41O_TAP_POST_NCO_I = 0, /* frame_len */
+  T41O_TAP_POST_NCO_Q = 1,
+  T41O_TAP_DEC_I = 2,      /* fft_length/2, after dec2 (+ level adjust in SSB/AM) */
+  T41O_TAP_DEC_Q = 3,
+  T41O_TAP_IFFT = 4,       /* 2*fft_length interleaved, after AGC */
+  T41O_TAP_DEMOD = 5       /* fft_length/2 audio before interpolation */
+};
+int t41o_channel_tap(const t41o_channel *ch, int which, float *dst, int maxlen);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,135 @@
+"""Independent float64 numpy/scipy model of the T41 RX chain.
+
+Purpose: catch *semantic* errors in oracle/t41_oracle.c (tap order, phase of the decimators,
+overlap-save indexing, state carry across frames, polyphase ordering).  It deliberately does
+NOT share structure with the oracle: it works on the whole multi-frame stream at once with
+scipy.signal.lfilter / upfirdn / np.convolve, where the oracle works frame by frame with CMSIS
+style state buffers.  Coefficients are taken as given (float32 values promoted to float64).
+
+Citations (relative to /root/reference/software/T41_SDR/): Process.cpp:117-134 (gains, DC-HP),
+:165-173 (IQ correction), Freq_Shift.cpp:42-141, Process.cpp:474-492, :498-605 (overlap-save),
+:615-761 (demod), :917-929 (interpolation, volume).
+"""
+import numpy as np
+from scipy import signal
+
+HP_DC = (0.927176191943378969, -0.927176191943378969, 0.854352383886757938)  # b0, b1, a1 (FIR.cpp:87-89)
+K_FM = 0.340447550238101026565118445432744920253753662109375  # Demod.h:7
+PI_F = float(np.float32(3.1415926535897932384626433832795))
+
+
+def _alpha_beta_mag(i, q):
+    a = float(np.float32(0.960433870103))
+    b = float(np.float32(0.397824734759))
+    ai, aq = np.abs(i), np.abs(q)
+    return np.where(ai > aq, a * ai + b * aq, a * aq + b * ai)
+
+
+def mask_taps(coeffs, N):
+    """impulse response the mask represents: N/2+1 complex taps, Q of the last one zeroed"""
+    m = np.asarray(coeffs["mask"], dtype=np.float64).reshape(N, 2)
+    h = np.fft.ifft(m[:, 0] + 1j * m[:, 1])
+    return h  # length N; taps beyond N/2 are ~0
+
+
+def run(I, Q, nco_freq, coeffs, *, fft_length=512, mode=0, FLoCut=200, FHiCut=3000,
+        rfGainAllBands=1, RFgain=1, iq_amp=1.0, iq_phase=0.0, audioVolume=30,
+        xmtMode=0, CWFreqShift=750):
+    """I, Q: 1-D float arrays, a whole number of frames (4*fft_length each). Returns audio."""
+    N = fft_length
+    D = N // 2
+    L = 4 * N
+    I = np.asarray(I, dtype=np.float64)
+    Q = np.asarray(Q, dtype=np.float64)
+    assert I.size % L == 0
+    nfr = I.size // L
+
+    g = float(np.float32(10.0 ** (float(np.float32(rfGainAllBands) / np.float32(20)))))
+    I = I * g
+    Q = Q * g
+
+    # DC high-pass with ONE state shared: per frame I then Q (Process.cpp:127-128)
+    b = [HP_DC[0], HP_DC[1]]
+    a = [1.0, -HP_DC[2]]
+    seq = np.empty(2 * I.size)
+    for f in range(nfr):
+        seq[2 * f * L:(2 * f + 1) * L] = I[f * L:(f + 1) * L]
+        seq[(2 * f + 1) * L:(2 * f + 2) * L] = Q[f * L:(f + 1) * L]
+    seq = signal.lfilter(b, a, seq)
+    for f in range(nfr):
+        I[f * L:(f + 1) * L] = seq[2 * f * L:(2 * f + 1) * L]
+        Q[f * L:(f + 1) * L] = seq[(2 * f + 1) * L:(2 * f + 2) * L]
+
+    I = I * float(RFgain)
+    Q = Q * float(RFgain)
+    if mode in (0, 1, 2):
+        I = I * (-float(np.float32(iq_amp)))
+        ph = float(np.float32(iq_phase))
+        if ph < 0.0:
+            Q = Q + ph * I
+        else:
+            I = I + ph * Q
+
+    n = np.arange(I.size)
+    z = (I + 1j * Q) * (1j ** (n % 4))  # FreqShift1: x[n] * j^n
+
+    side = 0
+    if xmtMode == 1:
+        side = CWFreqShift if mode == 1 else (-CWFreqShift if mode == 0 else 0)
+    inc = float(np.float32(2.0 * PI_F * (nco_freq + side) / 192000.0))
+    # amplitude recurrence of the quadrature oscillator (Freq_Shift.cpp:128-134)
+    r = np.empty(I.size)
+    rv = 1.0
+    for k in range(I.size):
+        r[k] = rv
+        rv = rv * (1.95 - rv * rv)
+        if abs(rv * rv - 0.95) < 1e-15:
+            r[k + 1:] = rv
+            break
+    osc = r * np.exp(1j * inc * (n + 1))
+    z = z * float(np.float32(1.1)) * np.conj(osc)
+
+    # decimators: y[m] = sum_d h[d] x[M m - d], h = reversed pCoeffs (CMSIS convention)
+    h1 = np.asarray(coeffs["dec1"], dtype=np.float64)[::-1]
+    h2 = np.asarray(coeffs["dec2"], dtype=np.float64)[::-1]
+    z = signal.lfilter(h1, [1.0], z)[::4]
+    z = signal.lfilter(h2, [1.0], z)[::2]
+
+    if mode == 3:  # NFM (Process.cpp:252-276, 716-727, 765-816)
+        out = np.empty(z.size)
+        li = lq = 0.0
+        for f in range(nfr):
+            blk = z[f * D:(f + 1) * D]
+            i_, q_ = blk.real, blk.imag
+            o = np.empty(D)
+            o[0] = K_FM * (i_[0] * (q_[0] - lq) - q_[0] * (i_[0] - li)) / (i_[0] ** 2 + q_[0] ** 2)
+            o[1:] = K_FM * (q_[1:] * i_[:-1] - i_[1:] * q_[:-1]) / (i_[1:] ** 2 + q_[1:] ** 2)
+            o[1:] = np.clip(o[1:], -1.0, 1.0)
+            # quirk: "last sample" is floats D-2, D-1 of the interleaved buffer = complex D/2-1
+            li, lq = i_[D // 2 - 1], q_[D // 2 - 1]
+            out[f * D:(f + 1) * D] = o
+        h = mask_taps(coeffs, N)
+        y = np.convolve(out, h)[:out.size] * 20.0
+        aud = y.real
+    else:
+        fk = (-float(np.float32(FLoCut)) * 0.001) if mode == 1 else (float(np.float32(FHiCut)) * 0.001)
+        fk = float(np.float32(fk))
+        vs = float(np.float32(7.0874 * fk ** (-1.232)))
+        z = z * vs
+        h = mask_taps(coeffs, N)
+        y = np.convolve(z, h)[:z.size] * 20.0
+        if mode in (0, 1):
+            aud = y.real.copy()
+        else:  # AM
+            m = _alpha_beta_mag(y.real, y.imag)
+            w = signal.lfilter([1.0, -1.0], [1.0, -float(np.float32(0.99))], m)
+            c = np.asarray(coeffs["biquad_lowpass1"], dtype=np.float64)
+            aud = signal.lfilter(c[:3], [1.0, -c[3], -c[4]], w)
+
+    g1 = np.asarray(coeffs["int1"], dtype=np.float64)[::-1]
+    g2 = np.asarray(coeffs["int2"], dtype=np.float64)[::-1]
+    a1 = signal.upfirdn(g1, aud, up=2)[:2 * aud.size]
+    a2 = signal.upfirdn(g2, a1, up=4)[:4 * a1.size]
+    x = float(np.float32(audioVolume / 100.0))
+    vol = float(np.float32(8.0) * np.float32(np.float32(5.0) * np.float32(x) ** 5))
+    return a2 * vol

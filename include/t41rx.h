@@ -1,0 +1,154 @@
+/*
+ * include/t41rx.h -- C ABI of the MI355X-native T41 receive DSP hot path.
+ *
+ * Drop-in boundary for tmr4/T41_SDR's `void ProcessIQData();` (Process.h:15, body
+ * Process.cpp:70-944).  The reference function takes no arguments: it reads/writes firmware
+ * globals.  Each entry point below names the reference global(s)/function it stands in for
+ * (file:line relative to /root/reference/software/T41_SDR/).  Plain pointers and sizes only;
+ * no C++/torch types cross this boundary.
+ *
+ * Data model: a context owns `n_channels` independent receive channels (the reference has
+ * exactly one: its static globals).  One `t41rx_process_*` call = one ProcessIQData() call on
+ * every channel (or `n_frames` consecutive calls), with all per-channel persistent state
+ * (FIR delay lines, NCO phase, overlap-save block, DC-block state ...) kept in device memory.
+ *
+ * Buffers (the reference's float_buffer_L / float_buffer_R, T41_SDR.ino:375-376, after the
+ * arm_q15_to_float conversion of Process.cpp:107-108, i.e. float_buffer_L = I, _R = Q):
+ *   I, Q   : const float [n_channels][n_frames * frame_len]   planar f32, read-only
+ *   audio  : float       [n_channels][n_frames * frame_len]   mono f32 @192 kS/s
+ *            (= float_buffer_L just before arm_float_to_q15, Process.cpp:929-936)
+ *   frame_len = BUFFER_SIZE * N_BLOCKS = 4 * fft_length  (2048 for FFT_LENGTH 512;
+ *   SDT.h:39,70, T41_SDR.ino:368).
+ *
+ * Errors: the reference returns nothing and hangs in while(1) on init failure
+ * (T41_SDR.ino:574-616).  Every function here returns an int status (0 = OK, <0 = error) and
+ * never aborts.  There is NO CPU fallback: if the HIP device or kernels are unavailable the
+ * call fails with T41RX_ERR_HIP.
+ */
+#ifndef T41RX_H
+#define T41RX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define T41RX_ABI_VERSION 1
+
+/* status codes */
+#define T41RX_OK 0
+#define T41RX_ERR_ARG (-1)        /* bad argument (null pointer, size, range) */
+#define T41RX_ERR_UNSUPPORTED (-2)/* valid in the reference but not built here */
+#define T41RX_ERR_HIP (-3)        /* HIP runtime / device error; see t41rx_last_error() */
+#define T41RX_ERR_NOMEM (-4)
+#define T41RX_ERR_STATE (-5)      /* blob / state size or version mismatch */
+
+/* demodulation modes: bands[currentBand].mode, SDT.h:58-68 */
+#define T41RX_DEMOD_USB 0
+#define T41RX_DEMOD_LSB 1
+#define T41RX_DEMOD_AM 2
+#define T41RX_DEMOD_NFM 3
+
+/* xmtMode, SDT.h:48-50 (only affects the CW side-tone offset of the NCO, Freq_Shift.cpp:108-120) */
+#define T41RX_SSB_MODE 0
+#define T41RX_CW_MODE 1
+#define T41RX_DATA_MODE 2
+
+/* The firmware globals ProcessIQData() reads, gathered into one POD (SURVEY 8b "Parameters"). */
+typedef struct t41rx_params {
+  int32_t fft_length;              /* FFT_LENGTH, SDT.h:39. 512 = reference; see t41rx_supported_fft_length */
+  int32_t mode;                    /* bands[currentBand].mode */
+  int32_t FLoCut;                  /* bands[currentBand].FLoCut [Hz], SDT.h:186 */
+  int32_t FHiCut;                  /* bands[currentBand].FHiCut [Hz], SDT.h:185 */
+  int32_t rfGainAllBands;          /* gwv.cpp:17, Process.cpp:117 */
+  int32_t RFgain;                  /* bands[currentBand].RFgain, Process.cpp:133 */
+  float   IQAmpCorrectionFactor;   /* IQAmpCorrectionFactor[currentBand], gwv.cpp:71 */
+  float   IQPhaseCorrectionFactor; /* IQPhaseCorrectionFactor[currentBand], gwv.cpp:72 */
+  int32_t AGCMode;                 /* gwv.cpp:15; 0 = off (fixed_gain 20, DSP_Fn.cpp:494-502) */
+  int32_t audioVolume;             /* gwv.cpp:16, Process.cpp:929 */
+  int32_t nfmFilterBW;             /* Filter.cpp:16, Process.cpp:259 */
+  int32_t xmtMode;                 /* gwv.cpp:22 */
+  int32_t CWFreqShift;             /* Freq_Shift.cpp:113-116 */
+  int32_t am_lpf_f0;               /* cutoff biquad_lowpass1 was designed for at boot, T41_SDR.ino:560-566 */
+} t41rx_params;
+
+typedef struct t41rx_ctx t41rx_ctx; /* opaque: coefficient arrays + per-channel state + device buffers */
+
+/* ---- library ---- */
+int         t41rx_abi_version(void);
+const char *t41rx_strerror(int status);
+const char *t41rx_last_error(void);          /* thread-local detail of the last failing call */
+int         t41rx_supported_fft_length(int fft_length); /* 1 if a kernel exists for it */
+
+/* Defaults of gwv.cpp:14-96 / bands[] T41_SDR.ino:145-168 (20 m row: USB, 200..3000 Hz) with
+ * AGCMode forced to 0. */
+void t41rx_default_params(t41rx_params *p);
+
+/* ---- coefficient design: host-side, no GPU needed ----
+ * The arrays CalcFilters() (Filter.cpp:235-249), InitFilterMask() (Filter.cpp:260-284),
+ * SetDecIntFilters() (Filter.cpp:396-438) and InitializeDataArrays() (T41_SDR.ino:560-566) leave
+ * behind, serialised as one blob:
+ *   header (8 x int32: magic, abi, fft_length, mode, 4 reserved) |
+ *   FIR_dec1_coeffs[28] | FIR_dec2_coeffs[46] | FIR_int1_coeffs[48] | FIR_int2_coeffs[32] |
+ *   biquad_lowpass1_coeffs[5] | scalars[11] | FIR_filter_mask[2*fft_length]      (all f32)
+ * This blob is what rank 0 broadcasts over RCCL after a filter change. */
+size_t t41rx_coeff_blob_bytes(int fft_length);
+int    t41rx_design_coeffs(const t41rx_params *p, void *blob, size_t blob_bytes);
+
+/* ---- context ---- */
+/* InitializeDataArrays() (T41_SDR.ino:473-667): allocate state for n_channels channels on HIP
+ * device `device_id`, power-on state, design + upload coefficients for *p. */
+int t41rx_create(t41rx_ctx **out, int device_id, int n_channels, const t41rx_params *p);
+int t41rx_destroy(t41rx_ctx *ctx);
+
+/* SetupMode()/CalcFilters() (Filter.cpp:235-249, 341-385): parameters changed between two
+ * ProcessIQData() calls.  Coefficients are re-designed and uploaded; like the reference, the
+ * streaming state (FIR delay lines etc.) is NOT reset.  fft_length cannot change. */
+int t41rx_set_params(t41rx_ctx *ctx, const t41rx_params *p);
+int t41rx_get_params(const t41rx_ctx *ctx, t41rx_params *p);
+
+/* Coefficient blob of the context (see t41rx_design_coeffs).  set = install a blob designed
+ * elsewhere (e.g. received by broadcast); it must match the context's fft_length. */
+int t41rx_get_coeffs(const t41rx_ctx *ctx, void *blob, size_t blob_bytes);
+int t41rx_set_coeffs(t41rx_ctx *ctx, const void *blob, size_t blob_bytes);
+
+/* NCOFreq (T41_SDR.ino:131, Tune.cpp:141-196), one value per channel, host array of n_channels.
+ * Phase-continuous: the oscillator state (Osc_Vect_Q/I, Freq_Shift.cpp:13-14) is kept. */
+int t41rx_set_nco_freq(t41rx_ctx *ctx, const int32_t *nco_freq_hz, int n);
+
+/* Power-on state: Osc_Vect_Q = 1, Osc_Vect_I = 0, all delay lines zero, first_block = 1
+ * (Freq_Shift.cpp:13-14, Process.cpp:42,47). */
+int t41rx_reset(t41rx_ctx *ctx);
+
+int t41rx_n_channels(const t41rx_ctx *ctx);
+int t41rx_frame_len(const t41rx_ctx *ctx);
+
+/* ---- the hot path: ProcessIQData() on every channel ----
+ * Device-pointer form: dI, dQ, dAudio are device pointers ([n_channels][n_frames*frame_len]);
+ * the kernel is enqueued on `hip_stream` (a hipStream_t, may be NULL = default stream) and the
+ * call returns without synchronising. */
+int t41rx_process_device(t41rx_ctx *ctx, const float *dI, const float *dQ, float *dAudio,
+                         int n_frames, void *hip_stream);
+/* Host-pointer form (the reference's calling convention: caller-owned host arrays): copies
+ * in, runs the same kernel, copies out, synchronises. */
+int t41rx_process_host(t41rx_ctx *ctx, const float *I, const float *Q, float *audio,
+                       int n_frames);
+
+/* ---- checkpoint of the streaming state (the reference never persists it) ---- */
+size_t t41rx_state_bytes(const t41rx_ctx *ctx);
+int    t41rx_get_state(t41rx_ctx *ctx, void *host_buf, size_t bytes);
+int    t41rx_set_state(t41rx_ctx *ctx, const void *host_buf, size_t bytes);
+
+/* ---- stage taps for parity debugging (device pointers, may each be NULL) ----
+ * When set, the next process calls also write, per channel and frame:
+ *   post_nco : [n_channels][n_frames*frame_len*2]  I/Q after FreqShift2 (planar: I then Q per frame)
+ *   dec      : [n_channels][n_frames*fft_length]   I/Q after decimate-by-8 (+ level adjust)
+ *   demod    : [n_channels][n_frames*fft_length/2] audio @24 kS/s before interpolation */
+int t41rx_set_debug_taps(t41rx_ctx *ctx, float *d_post_nco, float *d_dec, float *d_demod);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* T41RX_H */

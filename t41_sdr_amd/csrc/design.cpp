@@ -1,0 +1,250 @@
+// t41_sdr_amd/csrc/design.cpp -- host-side coefficient designer of the RX chain.
+//
+// Produces the arrays the reference recomputes on every filter change:
+//   CalcFIRCoeffs      FIR.cpp:908-980   (Kaiser-windowed sinc low-pass, 4 resampler filters)
+//   CalcCplxFIRCoeffs  FIR.cpp:1008-1065 (complex band-pass, 4-term Blackman-Harris)
+//   InitFilterMask     Filter.cpp:260-284 (zero-pad + forward complex FFT -> FIR_filter_mask)
+//   SetDecIntFilters   Filter.cpp:396-438
+//   SetIIRCoeffs       FIR.cpp:1076-1116 (AM low-pass biquad, designed once at boot)
+// plus the per-call scalars of Process.cpp (gains, level adjust, volume).
+// Runs on the host once per filter change; the blob is uploaded (and broadcast over RCCL in
+// multi-GPU runs).  All arithmetic keeps the reference's float/double operand types.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "rx_internal.hpp"
+
+namespace t41 {
+namespace {
+
+// FIR.h:10-16 -- the firmware redefines PI & friends as float literals
+constexpr float kPi = 3.1415926535897932384626433832795f;
+constexpr float kHalfPi = 1.5707963267948966192313216916398f;
+constexpr float kTwoPi = 6.283185307179586476925286766559f;
+constexpr float kFourPi = 2.0f * kTwoPi;
+constexpr float kSixPi = 3.0f * kTwoPi;
+
+constexpr float kDF1 = 4.0f, kDF = 8.0f;  // T41_SDR.ino:333-335
+constexpr float kAtt = 90.0f;             // n_att, T41_SDR.ino:336
+
+// modified Bessel I0 by its power series (Utility.cpp:211-229)
+float bessel_i0(float x) {
+  const float half = x / 2.0;
+  float sum = 1.0, term = 1.0, k = 1.0;
+  const float eps = 1e-9;
+  do {
+    float q = half / k;
+    q *= q;
+    term *= q;
+    sum += term;
+    k += 1.0;
+  } while (term >= eps * sum);
+  return sum;
+}
+
+// Utility.cpp:197-203
+float msinc(int m, float fc) {
+  const float x = m * kHalfPi;
+  return m == 0 ? 1.0f : sinf(x * fc) / (fc * x);
+}
+
+// Kaiser low-pass of CalcFIRCoeffs (type 0 only: the only type the RX path requests)
+void kaiser_lowpass(float *h, int ntaps, float fc_hz, float astop_db, float fs_hz) {
+  const float fc = fc_hz / fs_hz;
+  float beta;
+  if (astop_db < 20.96)
+    beta = 0.0;
+  else if (astop_db >= 50.0)
+    beta = 0.1102 * (astop_db - 8.71);
+  else
+    beta = 0.5842 * powf((astop_db - 20.96), 0.4) + 0.07886 * (astop_db - 20.96);
+  const float i0b = bessel_i0(beta);
+  const float fcf = fc * 2.0;
+  // the reference walks ii = -n, -n+2, ..., n-2: n taps of an (n+1)-point symmetric design
+  int tap = 0;
+  for (int ii = -ntaps; ii < ntaps; ii += 2, ++tap) {
+    const float x = (float)ii / (float)ntaps;
+    const float win = bessel_i0(beta * sqrtf(1.0f - x * x)) / i0b;
+    h[tap] = fcf * msinc(ii, fcf) * win;
+  }
+}
+
+// CalcCplxFIRCoeffs with FIR_filter_window == 1 (FIR.cpp:10)
+void complex_bandpass(std::vector<float> &ci, std::vector<float> &cq, int ntaps, float flo,
+                      float fhi, float fs) {
+  const float nFL = flo / fs, nFH = fhi / fs;
+  const float nFc = (nFH - nFL) / 2.0;
+  const float nFs = kPi * (nFH + nFL);
+  const float centre = 0.5 * (float)(ntaps - 1);
+  ci.assign(ntaps, 0.0f);
+  cq.assign(ntaps, 0.0f);
+  for (int i = 0; i < ntaps; ++i) {
+    const float x = (float)i - centre;
+    float z;
+    if (fabsf(x) < 0.01) {
+      z = 2.0 * nFc;
+    } else {
+      z = (float)sinf(kTwoPi * x * nFc) / (kPi * x) *
+          (0.35875 - 0.48829 * cosf((kTwoPi * i) / (ntaps - 1)) +
+           0.14128 * cosf((kFourPi * i) / (ntaps - 1)) - 0.01168 * cosf((kSixPi * i) / (ntaps - 1)));
+    }
+    ci[i] = z * cosf(nFs * x);
+    cq[i] = z * sinf(nFs * x);
+  }
+}
+
+// In-place forward complex FFT in f32 (the role arm_cfft_f32(maskS, ...) plays in
+// InitFilterMask).  Stockham autosort radix-2; twiddles rounded once from double.
+void fft_forward_f32(std::vector<float> &re, std::vector<float> &im) {
+  const int n = (int)re.size();
+  std::vector<float> tr(n), ti(n);
+  std::vector<float> wr(n / 2), wi(n / 2);
+  for (int k = 0; k < n / 2; ++k) {
+    const double a = -2.0 * M_PI * (double)k / (double)n;
+    wr[k] = (float)std::cos(a);
+    wi[k] = (float)std::sin(a);
+  }
+  float *xr = re.data(), *xi = im.data(), *yr = tr.data(), *yi = ti.data();
+  for (int half = n / 2, stride = 1; half >= 1; half >>= 1, stride <<= 1) {
+    // n = 2 * half * stride
+    for (int p = 0; p < half; ++p) {
+      const float cr = wr[p * stride], cw = wi[p * stride];
+      for (int q = 0; q < stride; ++q) {
+        const int ia = q + stride * p, ib = q + stride * (p + half);
+        const float ar = xr[ia], ai = xi[ia], br = xr[ib], bi = xi[ib];
+        const float dr = ar - br, di = ai - bi;
+        const int o0 = q + stride * (2 * p), o1 = q + stride * (2 * p + 1);
+        yr[o0] = ar + br;
+        yi[o0] = ai + bi;
+        yr[o1] = dr * cr - di * cw;
+        yi[o1] = dr * cw + di * cr;
+      }
+    }
+    std::swap(xr, yr);
+    std::swap(xi, yi);
+  }
+  if (xr != re.data()) {
+    std::memcpy(re.data(), xr, sizeof(float) * n);
+    std::memcpy(im.data(), xi, sizeof(float) * n);
+  }
+}
+
+// SetIIRCoeffs, low-pass branch
+void biquad_lowpass(float out[5], float f0, float q, float fs) {
+  if (f0 > fs / 2.0) f0 = fs / 2.0;
+  const float w0 = f0 * (kTwoPi / fs);
+  const float sn = sinf(w0);
+  const float alpha = sn / (q * 2.0);
+  const float cs = cosf(w0);
+  const float scale = 1.0 / (1.0 + alpha);
+  out[0] = ((1.0 - cs) / 2.0) * scale;
+  out[1] = (1.0 - cs) * scale;
+  out[2] = out[0];
+  out[3] = (2.0 * cs) * scale;
+  out[4] = (-1.0 + alpha) * scale;
+}
+
+}  // namespace
+
+bool params_valid(const t41rx_params &p, const char **why) {
+  auto fail = [&](const char *m) {
+    if (why) *why = m;
+    return false;
+  };
+  if (!(p.fft_length == 512 || p.fft_length == 1024 || p.fft_length == 2048 || p.fft_length == 4096))
+    return fail("fft_length must be 512, 1024, 2048 or 4096");
+  if (p.mode < T41RX_DEMOD_USB || p.mode > T41RX_DEMOD_NFM)
+    return fail("mode must be USB, LSB, AM or NFM");
+  if (p.FHiCut <= p.FLoCut) return fail("FHiCut must be greater than FLoCut");
+  if (p.FHiCut > 12000 || p.FLoCut < -12000) return fail("filter cut-offs beyond +-12 kHz (24 kS/s Nyquist)");
+  if (p.mode == T41RX_DEMOD_LSB && p.FLoCut >= 0) return fail("LSB needs FLoCut < 0 (level adjust uses pow(-FLoCut))");
+  if (p.mode != T41RX_DEMOD_LSB && p.mode != T41RX_DEMOD_NFM && p.FHiCut <= 0)
+    return fail("FHiCut must be > 0 (level adjust uses pow(FHiCut))");
+  if (p.audioVolume < 0 || p.audioVolume > 100) return fail("audioVolume out of 0..100");
+  if (p.nfmFilterBW <= 0 || p.nfmFilterBW > 96000) return fail("nfmFilterBW out of range");
+  if (p.xmtMode < T41RX_SSB_MODE || p.xmtMode > T41RX_DATA_MODE) return fail("bad xmtMode");
+  if (p.am_lpf_f0 <= 0) return fail("am_lpf_f0 must be > 0");
+  return true;
+}
+
+int design_blob(const t41rx_params &p, void *blob, size_t blob_bytes) {
+  const char *why = nullptr;
+  if (!blob) return T41RX_ERR_ARG;
+  if (!params_valid(p, &why)) return T41RX_ERR_ARG;
+  const int N = p.fft_length;
+  if (blob_bytes < blob_floats(N) * sizeof(float)) return T41RX_ERR_ARG;
+  std::memset(blob, 0, blob_floats(N) * sizeof(float));
+  BlobView v = blob_view(blob);
+  v.header[0] = (int32_t)kBlobMagic;
+  v.header[1] = T41RX_ABI_VERSION;
+  v.header[2] = N;
+  v.header[3] = p.mode;
+
+  // --- filter mask: (N/2+1)-tap complex band-pass at 24 kS/s, zero-padded, FFT'd ---
+  const int ntaps = N / 2 + 1;  // m_NumTaps, Filter.cpp:18
+  std::vector<float> ci, cq;
+  complex_bandpass(ci, cq, ntaps, (float)p.FLoCut, (float)p.FHiCut, (float)kSampleRate / kDF);
+  std::vector<float> re(N, 0.0f), im(N, 0.0f);
+  for (int i = 0; i < ntaps; ++i) {
+    re[i] = ci[i];
+    im[i] = cq[i];
+  }
+  // Filter.cpp:276-278 zero-fills interleaved floats N+1 .. 2N-1: that is im[N/2] and every
+  // re/im beyond it, so the last tap keeps its I part only.
+  im[N / 2] = 0.0f;
+  fft_forward_f32(re, im);
+  for (int k = 0; k < N; ++k) {
+    v.mask[2 * k] = re[k];
+    v.mask[2 * k + 1] = im[k];
+  }
+
+  // --- AM low-pass (boot-time design, never refreshed: SURVEY App. C #10) ---
+  biquad_lowpass(v.lp1, (float)p.am_lpf_f0, 1.3, (float)kSampleRate / kDF);
+
+  // --- resampler FIRs (Filter.cpp:396-417) ---
+  int bw = p.FHiCut;
+  if (bw < -p.FLoCut) bw = -p.FLoCut;
+  if (bw > 10000) bw = 10000;
+  kaiser_lowpass(v.dec1, kDec1Taps, (float)bw, kAtt, (float)kSampleRate);
+  kaiser_lowpass(v.dec2, kDec2Taps, (float)bw, kAtt, (float)(kSampleRate / kDF1));
+  kaiser_lowpass(v.int1, kInt1Taps, (float)bw, kAtt, (float)(kSampleRate / kDF1));
+  kaiser_lowpass(v.int2, kInt2Taps, (float)bw, kAtt, (float)kSampleRate);
+  if (p.mode == T41RX_DEMOD_NFM) {  // Process.cpp:259 -> Filter.cpp:429-438 (no 10 kHz cap)
+    kaiser_lowpass(v.dec1, kDec1Taps, (float)p.nfmFilterBW, kAtt, (float)kSampleRate);
+    kaiser_lowpass(v.dec2, kDec2Taps, (float)p.nfmFilterBW, kAtt, (float)(kSampleRate / kDF1));
+  }
+
+  // --- per-call scalars ---
+  float *s = v.scalars;
+  s[kScRfGain] = (float)std::pow(10, (float)p.rfGainAllBands / 20);  // Process.cpp:117
+  s[kScBandGain] = (float)p.RFgain;                                   // Process.cpp:133
+  s[kScNegIqAmp] = -p.IQAmpCorrectionFactor;                          // Process.cpp:166
+  s[kScIqPhase] = p.IQPhaseCorrectionFactor;
+  {
+    float fk;  // Process.cpp:482-490
+    if (p.mode == T41RX_DEMOD_LSB)
+      fk = -(float)p.FLoCut * 0.001;
+    else
+      fk = (float)p.FHiCut * 0.001;
+    s[kScLevel] = (p.mode == T41RX_DEMOD_NFM) ? 1.0f : (float)(7.0874 * std::pow(fk, -1.232));
+  }
+  s[kScFixedGain] = 20.0f;  // DSP_Fn.cpp:453
+  {
+    const float x = p.audioVolume / 100.0f;  // Process.cpp:955-967
+    const float ampl = 5 * x * x * x * x * x;
+    s[kScOutScale] = kDF * ampl;  // Process.cpp:929
+  }
+  s[kScIqCorrOn] = (p.mode == T41RX_DEMOD_USB || p.mode == T41RX_DEMOD_LSB || p.mode == T41RX_DEMOD_AM) ? 1.0f : 0.0f;
+  {
+    int side = 0;  // Freq_Shift.cpp:108-120
+    if (p.xmtMode == T41RX_CW_MODE) {
+      if (p.mode == 1) side = p.CWFreqShift;
+      else if (p.mode == 0) side = -p.CWFreqShift;
+    }
+    s[kScSideTone] = (float)side;
+  }
+  return T41RX_OK;
+}
+
+}  // namespace t41

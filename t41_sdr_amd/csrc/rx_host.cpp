@@ -1,0 +1,427 @@
+// t41_sdr_amd/csrc/rx_host.cpp -- host side of the C ABI in include/t41rx.h.
+//
+// Owns what the reference keeps in firmware globals: the coefficient arrays
+// (FIR_dec1_coeffs ... FIR_filter_mask, T41_SDR.ino:398-399, Filter.cpp:39-41), the CMSIS
+// instance state (T41_SDR.ino:384-397), the oscillator state (Freq_Shift.cpp:13-14) and the
+// overlap-save block (T41_SDR.ino:403-404) -- here per channel and resident in HBM.
+// There is no CPU implementation of the path in this library: without a HIP device every
+// create/process call fails with T41RX_ERR_HIP.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "rx_internal.hpp"
+#include "rx_kernels.hpp"
+
+using namespace t41;
+
+struct t41rx_ctx {
+  int device = 0;
+  int nchan = 0;
+  t41rx_params params{};
+  std::vector<float> blob;       // canonical coefficient blob (host)
+  std::vector<int32_t> nco_hz;   // NCOFreq per channel (host)
+  float *d_state = nullptr;      // [nchan][state_floats]
+  DevCoef *d_coef = nullptr;
+  float2 *d_tab = nullptr;
+  ChanNco *d_nco = nullptr;
+  float *dbg_nco = nullptr, *dbg_dec = nullptr, *dbg_demod = nullptr;
+  // staging for t41rx_process_host
+  float *d_in_i = nullptr, *d_in_q = nullptr, *d_out = nullptr;
+  size_t staging_floats = 0;
+};
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string &msg) {
+  g_last_error = msg;
+  return code;
+}
+int hip_fail(hipError_t e, const char *what) {
+  return fail(T41RX_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(expr)                                  \
+  do {                                                 \
+    hipError_t e__ = (expr);                           \
+    if (e__ != hipSuccess) return hip_fail(e__, #expr); \
+  } while (0)
+
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    ok = (hipSetDevice(dev) == hipSuccess);
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+constexpr float kPiF = 3.1415926535897932384626433832795f;  // FIR.h:10
+
+// FreqShift2's per-call constants (Freq_Shift.cpp:121-124) turned into what the kernel needs:
+// the rotation per sample as a 0.64 fixed-point fraction of a turn, the steady-state
+// amplitude of the oscillator's gain loop, and the eight per-lane sample offsets.
+ChanNco make_nco(int32_t nco_freq_hz, int side_tone_hz) {
+  ChanNco n{};
+  const long f = (long)nco_freq_hz + (long)side_tone_hz;
+  const float inc = (float)(2.0 * kPiF * f / 192000.0);  // NCO_INC (float32_t)
+  const double c = std::cos((double)inc), s = std::sin((double)inc);  // OSC_COS / OSC_SIN
+  const long double ang = atan2l((long double)s, (long double)c);
+  long double turns = ang / (2.0L * 3.14159265358979323846264338327950288L);
+  if (turns < 0.0L) turns += 1.0L;
+  const long double scaled = floorl(turns * 18446744073709551616.0L + 0.5L);
+  n.phase_inc = (scaled >= 18446744073709551616.0L) ? 0ull : (uint64_t)scaled;
+  n.w_abs = (double)hypotl((long double)c, (long double)s);
+  // fixed point of r <- r (1.95 - r^2) |W|  (Freq_Shift.cpp:130-134)
+  n.r_star_sq = 1.95 - 1.0 / n.w_abs;
+  const double amp = (double)1.1f * std::sqrt(n.r_star_sq) * n.w_abs;  // freqAdjFactor * |Osc|
+  for (int k = 0; k < 8; ++k) {
+    n.wk[k][0] = (float)(amp * (double)cosl(ang * k));
+    n.wk[k][1] = (float)(amp * (double)sinl(ang * k));
+  }
+  return n;
+}
+
+int upload_nco(t41rx_ctx *ctx) {
+  std::vector<ChanNco> h((size_t)ctx->nchan);
+  const int side = (int)blob_view(ctx->blob.data()).scalars[kScSideTone];
+  for (int i = 0; i < ctx->nchan; ++i) h[(size_t)i] = make_nco(ctx->nco_hz[(size_t)i], side);
+  HIP_TRY(hipMemcpy(ctx->d_nco, h.data(), sizeof(ChanNco) * h.size(), hipMemcpyHostToDevice));
+  return T41RX_OK;
+}
+
+// blob -> device constant block + lane-ordered tables
+int upload_coeffs(t41rx_ctx *ctx) {
+  const int N = ctx->params.fft_length;
+  BlobView v = blob_view(ctx->blob.data());
+  DevCoef dc;
+  std::memset(&dc, 0, sizeof(dc));
+  std::memcpy(dc.dec1, v.dec1, sizeof(float) * kDec1Taps);
+  std::memcpy(dc.dec2, v.dec2, sizeof(float) * kDec2Taps);
+  std::memcpy(dc.int1, v.int1, sizeof(float) * kInt1Taps);
+  std::memcpy(dc.int2, v.int2, sizeof(float) * kInt2Taps);
+  std::memcpy(dc.lp1, v.lp1, sizeof(float) * 5);
+  std::memcpy(dc.sc, v.scalars, sizeof(float) * kNumScalars);
+  HIP_TRY(hipMemcpy(ctx->d_coef, &dc, sizeof(dc), hipMemcpyHostToDevice));
+
+  if (N != 512) return fail(T41RX_ERR_UNSUPPORTED, "only fft_length 512 has a kernel");
+  std::vector<float2> tab((size_t)kTabEntries512);
+  const float invN = 1.0f / (float)N;  // exact power of two: folding it into the mask is lossless
+  for (int r = 0; r < 8; ++r)
+    for (int l = 0; l < 64; ++l) {
+      const int k = l + 64 * r;
+      tab[(size_t)(kTabMask + 64 * r + l)] = make_float2(v.mask[2 * k] * invN, v.mask[2 * k + 1] * invN);
+    }
+  const double two_pi = 6.283185307179586476925286766559;
+  for (int q = 1; q < 8; ++q)
+    for (int l = 0; l < 64; ++l) {
+      const double a1 = -two_pi * (double)(l * q) / 512.0;
+      const double a2 = -two_pi * (double)((l & 7) * q) / 64.0;
+      tab[(size_t)(kTabTw1 + 64 * (q - 1) + l)] = make_float2((float)std::cos(a1), (float)std::sin(a1));
+      tab[(size_t)(kTabTw2 + 64 * (q - 1) + l)] = make_float2((float)std::cos(a2), (float)std::sin(a2));
+    }
+  for (int i = 0; i < 256; ++i) {
+    const double a = two_pi * (double)i / 256.0;
+    tab[(size_t)(kTabSinCos + i)] = make_float2((float)std::cos(a), (float)std::sin(a));
+  }
+  HIP_TRY(hipMemcpy(ctx->d_tab, tab.data(), sizeof(float2) * tab.size(), hipMemcpyHostToDevice));
+  return T41RX_OK;
+}
+
+int reset_state(t41rx_ctx *ctx) {
+  const size_t sf = state_floats(ctx->params.fft_length);
+  std::vector<float> h(sf * (size_t)ctx->nchan, 0.0f);
+  for (int c = 0; c < ctx->nchan; ++c) {
+    NcoState ns;
+    ns.phase = 0;  // Osc_Vect_Q = 1, Osc_Vect_I = 0 (Freq_Shift.cpp:13-14)
+    ns.r = 1.0;
+    std::memcpy(h.data() + sf * (size_t)c + kStNco, &ns, sizeof(ns));
+  }
+  HIP_TRY(hipMemcpy(ctx->d_state, h.data(), sizeof(float) * h.size(), hipMemcpyHostToDevice));
+  return T41RX_OK;
+}
+
+void free_ctx(t41rx_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipFree(ctx->d_state);
+  (void)hipFree(ctx->d_coef);
+  (void)hipFree(ctx->d_tab);
+  (void)hipFree(ctx->d_nco);
+  (void)hipFree(ctx->d_in_i);
+  (void)hipFree(ctx->d_in_q);
+  (void)hipFree(ctx->d_out);
+  delete ctx;
+}
+
+}  // namespace
+
+extern "C" {
+
+int t41rx_abi_version(void) { return T41RX_ABI_VERSION; }
+
+const char *t41rx_strerror(int status) {
+  switch (status) {
+    case T41RX_OK: return "ok";
+    case T41RX_ERR_ARG: return "invalid argument";
+    case T41RX_ERR_UNSUPPORTED: return "not supported by this build";
+    case T41RX_ERR_HIP: return "HIP runtime/device error";
+    case T41RX_ERR_NOMEM: return "out of memory";
+    case T41RX_ERR_STATE: return "blob/state mismatch";
+    default: return "unknown status";
+  }
+}
+
+const char *t41rx_last_error(void) { return g_last_error.c_str(); }
+
+int t41rx_supported_fft_length(int fft_length) { return fft_length == 512 ? 1 : 0; }
+
+void t41rx_default_params(t41rx_params *p) {
+  if (!p) return;
+  std::memset(p, 0, sizeof(*p));
+  p->fft_length = 512;               // SDT.h:39
+  p->mode = T41RX_DEMOD_USB;         // bands[] 20 m row, T41_SDR.ino:163
+  p->FLoCut = 200;
+  p->FHiCut = 3000;
+  p->rfGainAllBands = 1;             // gwv.cpp:17
+  p->RFgain = 1;                     // bands[].RFgain
+  p->IQAmpCorrectionFactor = 1.0f;   // gwv.cpp:71
+  p->IQPhaseCorrectionFactor = 0.0f; // gwv.cpp:72
+  p->AGCMode = 0;                    // firmware default is 1 (gwv.cpp:15); 0 = fixed gain
+  p->audioVolume = 30;               // gwv.cpp:16
+  p->nfmFilterBW = 12000;            // Filter.cpp:16
+  p->xmtMode = T41RX_SSB_MODE;       // gwv.cpp:22
+  p->CWFreqShift = 750;
+  p->am_lpf_f0 = 3000;               // boot band 40 m: max(FHiCut, -FLoCut) = 3000
+}
+
+size_t t41rx_coeff_blob_bytes(int fft_length) {
+  if (!(fft_length == 512 || fft_length == 1024 || fft_length == 2048 || fft_length == 4096)) return 0;
+  return blob_floats(fft_length) * sizeof(float);
+}
+
+int t41rx_design_coeffs(const t41rx_params *p, void *blob, size_t blob_bytes) {
+  if (!p || !blob) return fail(T41RX_ERR_ARG, "null argument");
+  const char *why = nullptr;
+  if (!params_valid(*p, &why)) return fail(T41RX_ERR_ARG, why ? why : "bad params");
+  if (blob_bytes < t41rx_coeff_blob_bytes(p->fft_length)) return fail(T41RX_ERR_ARG, "blob buffer too small");
+  return design_blob(*p, blob, blob_bytes);
+}
+
+int t41rx_create(t41rx_ctx **out, int device_id, int n_channels, const t41rx_params *p) {
+  if (!out || !p) return fail(T41RX_ERR_ARG, "null argument");
+  *out = nullptr;
+  if (n_channels <= 0) return fail(T41RX_ERR_ARG, "n_channels must be > 0");
+  const char *why = nullptr;
+  if (!params_valid(*p, &why)) return fail(T41RX_ERR_ARG, why ? why : "bad params");
+  if (p->AGCMode != 0) return fail(T41RX_ERR_UNSUPPORTED, "AGCMode != 0 (look-ahead AGC) is not built yet");
+  if (!(p->mode == T41RX_DEMOD_USB || p->mode == T41RX_DEMOD_LSB))
+    return fail(T41RX_ERR_UNSUPPORTED, "only USB/LSB demodulation has a kernel yet");
+  if (!t41rx_supported_fft_length(p->fft_length)) return fail(T41RX_ERR_UNSUPPORTED, "no kernel for this fft_length");
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device_id < 0 || device_id >= ndev) return fail(T41RX_ERR_HIP, "no such HIP device");
+  DeviceGuard g(device_id);
+  if (!g.ok) return fail(T41RX_ERR_HIP, "hipSetDevice failed");
+
+  t41rx_ctx *ctx = new (std::nothrow) t41rx_ctx();
+  if (!ctx) return fail(T41RX_ERR_NOMEM, "host allocation failed");
+  ctx->device = device_id;
+  ctx->nchan = n_channels;
+  ctx->params = *p;
+  ctx->blob.assign(blob_floats(p->fft_length), 0.0f);
+  ctx->nco_hz.assign((size_t)n_channels, 0);
+  int rc = design_blob(*p, ctx->blob.data(), ctx->blob.size() * sizeof(float));
+  if (rc != T41RX_OK) {
+    free_ctx(ctx);
+    return fail(rc, "coefficient design failed");
+  }
+  hipError_t e;
+  const size_t sbytes = sizeof(float) * state_floats(p->fft_length) * (size_t)n_channels;
+  if ((e = hipMalloc((void **)&ctx->d_state, sbytes)) != hipSuccess ||
+      (e = hipMalloc((void **)&ctx->d_coef, sizeof(DevCoef))) != hipSuccess ||
+      (e = hipMalloc((void **)&ctx->d_tab, sizeof(float2) * kTabEntries512)) != hipSuccess ||
+      (e = hipMalloc((void **)&ctx->d_nco, sizeof(ChanNco) * (size_t)n_channels)) != hipSuccess) {
+    free_ctx(ctx);
+    return hip_fail(e, "hipMalloc");
+  }
+  if ((rc = upload_coeffs(ctx)) != T41RX_OK || (rc = upload_nco(ctx)) != T41RX_OK ||
+      (rc = reset_state(ctx)) != T41RX_OK) {
+    free_ctx(ctx);
+    return rc;
+  }
+  *out = ctx;
+  return T41RX_OK;
+}
+
+int t41rx_destroy(t41rx_ctx *ctx) {
+  if (!ctx) return T41RX_OK;
+  DeviceGuard g(ctx->device);
+  (void)hipDeviceSynchronize();
+  free_ctx(ctx);
+  return T41RX_OK;
+}
+
+int t41rx_set_params(t41rx_ctx *ctx, const t41rx_params *p) {
+  if (!ctx || !p) return fail(T41RX_ERR_ARG, "null argument");
+  const char *why = nullptr;
+  if (!params_valid(*p, &why)) return fail(T41RX_ERR_ARG, why ? why : "bad params");
+  if (p->fft_length != ctx->params.fft_length) return fail(T41RX_ERR_ARG, "fft_length cannot change on a live context");
+  if (p->AGCMode != 0) return fail(T41RX_ERR_UNSUPPORTED, "AGCMode != 0 is not built yet");
+  if (!(p->mode == T41RX_DEMOD_USB || p->mode == T41RX_DEMOD_LSB))
+    return fail(T41RX_ERR_UNSUPPORTED, "only USB/LSB demodulation has a kernel yet");
+  std::vector<float> nb(ctx->blob.size());
+  int rc = design_blob(*p, nb.data(), nb.size() * sizeof(float));
+  if (rc != T41RX_OK) return fail(rc, "coefficient design failed");
+  DeviceGuard g(ctx->device);
+  HIP_TRY(hipDeviceSynchronize());
+  ctx->blob.swap(nb);
+  ctx->params = *p;
+  if ((rc = upload_coeffs(ctx)) != T41RX_OK) return rc;
+  return upload_nco(ctx);  // the CW side-tone offset may have changed
+}
+
+int t41rx_get_params(const t41rx_ctx *ctx, t41rx_params *p) {
+  if (!ctx || !p) return fail(T41RX_ERR_ARG, "null argument");
+  *p = ctx->params;
+  return T41RX_OK;
+}
+
+int t41rx_get_coeffs(const t41rx_ctx *ctx, void *blob, size_t blob_bytes) {
+  if (!ctx || !blob) return fail(T41RX_ERR_ARG, "null argument");
+  const size_t need = ctx->blob.size() * sizeof(float);
+  if (blob_bytes < need) return fail(T41RX_ERR_ARG, "blob buffer too small");
+  std::memcpy(blob, ctx->blob.data(), need);
+  return T41RX_OK;
+}
+
+int t41rx_set_coeffs(t41rx_ctx *ctx, const void *blob, size_t blob_bytes) {
+  if (!ctx || !blob) return fail(T41RX_ERR_ARG, "null argument");
+  const size_t need = ctx->blob.size() * sizeof(float);
+  if (blob_bytes < need) return fail(T41RX_ERR_STATE, "blob too small for this context");
+  const int32_t *h = reinterpret_cast<const int32_t *>(blob);
+  if ((uint32_t)h[0] != kBlobMagic || h[1] != T41RX_ABI_VERSION) return fail(T41RX_ERR_STATE, "bad blob header");
+  if (h[2] != ctx->params.fft_length) return fail(T41RX_ERR_STATE, "blob fft_length differs from the context");
+  if (!(h[3] == T41RX_DEMOD_USB || h[3] == T41RX_DEMOD_LSB)) return fail(T41RX_ERR_UNSUPPORTED, "blob mode has no kernel yet");
+  DeviceGuard g(ctx->device);
+  HIP_TRY(hipDeviceSynchronize());
+  std::memcpy(ctx->blob.data(), blob, need);
+  ctx->params.mode = h[3];
+  int rc = upload_coeffs(ctx);
+  if (rc != T41RX_OK) return rc;
+  return upload_nco(ctx);
+}
+
+int t41rx_set_nco_freq(t41rx_ctx *ctx, const int32_t *nco_freq_hz, int n) {
+  if (!ctx || !nco_freq_hz) return fail(T41RX_ERR_ARG, "null argument");
+  if (n != ctx->nchan) return fail(T41RX_ERR_ARG, "n must equal n_channels");
+  for (int i = 0; i < n; ++i)
+    if (nco_freq_hz[i] < -96000 || nco_freq_hz[i] > 96000) return fail(T41RX_ERR_ARG, "NCOFreq beyond +-Fs/2");
+  DeviceGuard g(ctx->device);
+  HIP_TRY(hipDeviceSynchronize());
+  std::memcpy(ctx->nco_hz.data(), nco_freq_hz, sizeof(int32_t) * (size_t)n);
+  return upload_nco(ctx);
+}
+
+int t41rx_reset(t41rx_ctx *ctx) {
+  if (!ctx) return fail(T41RX_ERR_ARG, "null argument");
+  DeviceGuard g(ctx->device);
+  HIP_TRY(hipDeviceSynchronize());
+  return reset_state(ctx);
+}
+
+int t41rx_n_channels(const t41rx_ctx *ctx) { return ctx ? ctx->nchan : T41RX_ERR_ARG; }
+int t41rx_frame_len(const t41rx_ctx *ctx) { return ctx ? 4 * ctx->params.fft_length : T41RX_ERR_ARG; }
+
+int t41rx_process_device(t41rx_ctx *ctx, const float *dI, const float *dQ, float *dAudio, int n_frames,
+                         void *hip_stream) {
+  if (!ctx || !dI || !dQ || !dAudio) return fail(T41RX_ERR_ARG, "null argument");
+  if (n_frames <= 0) return fail(T41RX_ERR_ARG, "n_frames must be > 0");
+  if ((reinterpret_cast<uintptr_t>(dI) | reinterpret_cast<uintptr_t>(dQ) | reinterpret_cast<uintptr_t>(dAudio)) & 15u)
+    return fail(T41RX_ERR_ARG, "I/Q/audio device pointers must be 16-byte aligned");
+  DeviceGuard g(ctx->device);
+  if (!g.ok) return fail(T41RX_ERR_HIP, "hipSetDevice failed");
+  RxArgs a{};
+  a.I = dI;
+  a.Q = dQ;
+  a.out = dAudio;
+  a.state = ctx->d_state;
+  a.coef = ctx->d_coef;
+  a.tab = ctx->d_tab;
+  a.nco = ctx->d_nco;
+  a.nchan = ctx->nchan;
+  a.nframes = n_frames;
+  a.dbg_nco = ctx->dbg_nco;
+  a.dbg_dec = ctx->dbg_dec;
+  a.dbg_demod = ctx->dbg_demod;
+  hipError_t e = launch_rx(a, ctx->params.fft_length, ctx->params.mode, (hipStream_t)hip_stream);
+  if (e != hipSuccess) return hip_fail(e, "kernel launch");
+  return T41RX_OK;
+}
+
+int t41rx_process_host(t41rx_ctx *ctx, const float *I, const float *Q, float *audio, int n_frames) {
+  if (!ctx || !I || !Q || !audio) return fail(T41RX_ERR_ARG, "null argument");
+  if (n_frames <= 0) return fail(T41RX_ERR_ARG, "n_frames must be > 0");
+  DeviceGuard g(ctx->device);
+  if (!g.ok) return fail(T41RX_ERR_HIP, "hipSetDevice failed");
+  const size_t nfl = (size_t)ctx->nchan * (size_t)n_frames * (size_t)(4 * ctx->params.fft_length);
+  if (nfl > ctx->staging_floats) {
+    (void)hipFree(ctx->d_in_i);
+    (void)hipFree(ctx->d_in_q);
+    (void)hipFree(ctx->d_out);
+    ctx->d_in_i = ctx->d_in_q = ctx->d_out = nullptr;
+    ctx->staging_floats = 0;
+    HIP_TRY(hipMalloc((void **)&ctx->d_in_i, nfl * sizeof(float)));
+    HIP_TRY(hipMalloc((void **)&ctx->d_in_q, nfl * sizeof(float)));
+    HIP_TRY(hipMalloc((void **)&ctx->d_out, nfl * sizeof(float)));
+    ctx->staging_floats = nfl;
+  }
+  HIP_TRY(hipMemcpy(ctx->d_in_i, I, nfl * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(ctx->d_in_q, Q, nfl * sizeof(float), hipMemcpyHostToDevice));
+  int rc = t41rx_process_device(ctx, ctx->d_in_i, ctx->d_in_q, ctx->d_out, n_frames, nullptr);
+  if (rc != T41RX_OK) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(audio, ctx->d_out, nfl * sizeof(float), hipMemcpyDeviceToHost));
+  return T41RX_OK;
+}
+
+size_t t41rx_state_bytes(const t41rx_ctx *ctx) {
+  if (!ctx) return 0;
+  return sizeof(float) * state_floats(ctx->params.fft_length) * (size_t)ctx->nchan;
+}
+
+int t41rx_get_state(t41rx_ctx *ctx, void *host_buf, size_t bytes) {
+  if (!ctx || !host_buf) return fail(T41RX_ERR_ARG, "null argument");
+  if (bytes < t41rx_state_bytes(ctx)) return fail(T41RX_ERR_STATE, "state buffer too small");
+  DeviceGuard g(ctx->device);
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(host_buf, ctx->d_state, t41rx_state_bytes(ctx), hipMemcpyDeviceToHost));
+  return T41RX_OK;
+}
+
+int t41rx_set_state(t41rx_ctx *ctx, const void *host_buf, size_t bytes) {
+  if (!ctx || !host_buf) return fail(T41RX_ERR_ARG, "null argument");
+  if (bytes != t41rx_state_bytes(ctx)) return fail(T41RX_ERR_STATE, "state size mismatch");
+  DeviceGuard g(ctx->device);
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(ctx->d_state, host_buf, bytes, hipMemcpyHostToDevice));
+  return T41RX_OK;
+}
+
+int t41rx_set_debug_taps(t41rx_ctx *ctx, float *d_post_nco, float *d_dec, float *d_demod) {
+  if (!ctx) return fail(T41RX_ERR_ARG, "null argument");
+  ctx->dbg_nco = d_post_nco;
+  ctx->dbg_dec = d_dec;
+  ctx->dbg_demod = d_demod;
+  return T41RX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,101 @@
+// t41_sdr_amd/csrc/rx_internal.hpp -- layouts shared by the host side and the HIP kernels.
+// Product code: must not include or link anything from oracle/.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+#include "../../include/t41rx.h"
+
+namespace t41 {
+
+constexpr int kSampleRate = 192000;  // T41_SDR.ino:129
+constexpr int kDec1Taps = 28;        // n_dec1_taps, T41_SDR.ino:344
+constexpr int kDec2Taps = 46;        // n_dec2_taps, T41_SDR.ino:345
+constexpr int kInt1Taps = 48;        // T41_SDR.ino:595-603 (L=2, phase length 24)
+constexpr int kInt2Taps = 32;        // T41_SDR.ino:608-616 (L=4, phase length 8)
+
+// ---- coefficient blob (host, canonical reference layout; what RCCL broadcasts) ----
+constexpr uint32_t kBlobMagic = 0x54343152u;  // "T41R"
+constexpr int kBlobHeaderInts = 8;
+constexpr int kNumScalars = 11;
+enum Scalar {
+  kScRfGain = 0,      // (float)pow(10, rfGainAllBands/20), Process.cpp:117
+  kScBandGain = 1,    // (float)bands[].RFgain, Process.cpp:133
+  kScNegIqAmp = 2,    // -IQAmpCorrectionFactor, Process.cpp:166
+  kScIqPhase = 3,     // IQPhaseCorrectionFactor, Utility.cpp:178
+  kScLevel = 4,       // volScaleFactor, Process.cpp:490
+  kScFixedGain = 5,   // fixed_gain, DSP_Fn.cpp:453
+  kScOutScale = 6,    // DF * VolumeToAmplification(audioVolume), Process.cpp:929
+  kScIqCorrOn = 7,    // 1 when mode in {USB, LSB, AM}, Process.cpp:165-173
+  kScSideTone = 8,    // sideToneShift [Hz], Freq_Shift.cpp:108-120
+};
+struct BlobView {
+  int32_t *header;
+  float *dec1, *dec2, *int1, *int2, *lp1, *scalars, *mask;
+};
+constexpr size_t blob_floats(int fft_length) {
+  return kBlobHeaderInts + kDec1Taps + kDec2Taps + kInt1Taps + kInt2Taps + 5 + kNumScalars +
+         2 * (size_t)fft_length;
+}
+inline BlobView blob_view(void *blob) {
+  BlobView v;
+  v.header = reinterpret_cast<int32_t *>(blob);
+  float *f = reinterpret_cast<float *>(blob) + kBlobHeaderInts;
+  v.dec1 = f;
+  v.dec2 = v.dec1 + kDec1Taps;
+  v.int1 = v.dec2 + kDec2Taps;
+  v.int2 = v.int1 + kInt1Taps;
+  v.lp1 = v.int2 + kInt2Taps;
+  v.scalars = v.lp1 + 5;
+  v.mask = v.scalars + kNumScalars;
+  return v;
+}
+
+// host designer (design.cpp)
+int design_blob(const t41rx_params &p, void *blob, size_t blob_bytes);
+bool params_valid(const t41rx_params &p, const char **why);
+
+// ---- device-side constant block (one per context) ----
+// scalar-loadable coefficient struct, uniform for every wave
+struct DevCoef {
+  float dec1[kDec1Taps];
+  float dec2[48];  // 46 used
+  float int1[kInt1Taps];
+  float int2[kInt2Taps];
+  float lp1[8];    // 5 used
+  float sc[16];    // Scalar enum
+};
+
+// per-channel NCO constants, recomputed on the host when NCOFreq changes (set_nco_freq)
+struct ChanNco {
+  uint64_t phase_inc;  // rotation per sample in turns, 0.64 fixed point
+  float wk[8][2];      // 1.1 * A * e^{j 2 pi k dphi}, k = 0..7 (A = steady |Osc|)
+  double r_star_sq;    // steady-state |Osc_Vect|^2 (fixed point of the amplitude loop)
+  double w_abs;        // |cos + j sin| of the rotation constant
+};
+static_assert(sizeof(ChanNco) == 8 + 64 + 16, "ChanNco layout");
+
+// ---- per-channel streaming state in HBM (floats), one contiguous record per channel ----
+// Offsets in floats; every section 16-byte aligned.  "pad" entries keep the delay lines
+// float4-aligned with the newest history sample adjacent to the first new sample.
+constexpr int kStDec1I = 0;     // 28: [0] pad, [1..27] = last 27 post-NCO I samples
+constexpr int kStDec1Q = 28;    // 28
+constexpr int kStDec2I = 56;    // 48: [0..2] pad, [3..47] = last 45 dec1 outputs
+constexpr int kStDec2Q = 104;   // 48
+constexpr int kStInt1 = 152;    // 24: [0] pad, [1..23] = last 23 demodulated samples
+constexpr int kStInt2 = 176;    // 8:  [0] pad, [1..7]  = last 7 int1 outputs
+constexpr int kStMisc = 184;    // 16 floats: see below
+constexpr int kMiscDc = 0;      // DC-HP d1 (HP_DC_Butter_state2[0]); [1] = d2 (always 0)
+constexpr int kMiscWold = 2;    // AM DC-block wold, Process.cpp:73
+constexpr int kMiscNfmI = 4;    // nfmdemod last_sample_i/q, Demod.cpp:221-222
+constexpr int kMiscNfmQ = 5;
+constexpr int kMiscLp1 = 8;     // biquad_lowpass1_state[4]
+constexpr int kStNco = 200;     // 8 floats = uint64 phase (turns, 0.64) + double |V|^2... see NcoState
+constexpr int kStOverlap = 256; // fft_length floats: last_sample_buffer_L/R as [k][lane] (re,im)
+struct NcoState {
+  uint64_t phase;  // arg(Osc_Vect_Q + j Osc_Vect_I) in turns, 0.64 fixed point
+  double r;        // |Osc_Vect|
+};
+constexpr size_t state_floats(int fft_length) { return (size_t)kStOverlap + (size_t)fft_length; }
+
+}  // namespace t41

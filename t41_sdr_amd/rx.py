@@ -1,0 +1,157 @@
+"""Host-side mirror of the reference's receive-path interface, over the C ABI.
+
+The reference (tmr4/T41_SDR) drives the path through globals and three functions:
+  InitializeDataArrays()  T41_SDR.ino:473   -> RxChain(...)
+  SetupMode()/CalcFilters()  Filter.cpp:235-249,341-385  -> RxChain.CalcFilters(**changes)
+  ProcessIQData()  Process.cpp:70           -> RxChain.ProcessIQData(float_buffer_L, float_buffer_R)
+Names and argument meanings follow the firmware (bands[].FLoCut, NCOFreq, audioVolume ...).
+PyTorch is used only as the owner of device memory / streams; all arithmetic happens in
+libt41rx.so (HIP).  No CPU fallback exists.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import DEMOD_AM, DEMOD_LSB, DEMOD_NFM, DEMOD_USB, Params, T41RxError, check  # noqa: F401
+
+
+def default_params(**overrides):
+    """gwv.cpp:14-96 / bands[] defaults (20 m row) with AGCMode = 0."""
+    lib = _lib.load()
+    p = Params()
+    lib.t41rx_default_params(C.byref(p))
+    for k, v in overrides.items():
+        if not hasattr(p, k):
+            raise AttributeError("t41rx_params has no field %r" % k)
+        setattr(p, k, v)
+    return p
+
+
+def design_coeffs(params):
+    """CalcFilters() on the host: returns the coefficient blob (bytes-like numpy uint8)."""
+    lib = _lib.load()
+    n = lib.t41rx_coeff_blob_bytes(params.fft_length)
+    if n == 0:
+        raise T41RxError(_lib.ERR_ARG, "unsupported fft_length %d" % params.fft_length)
+    blob = np.zeros(n, dtype=np.uint8)
+    check(lib.t41rx_design_coeffs(C.byref(params), blob.ctypes.data_as(C.c_void_p), n))
+    return blob
+
+
+def blob_fields(blob, fft_length):
+    """Split a coefficient blob into the reference's arrays (numpy views)."""
+    f = np.frombuffer(blob, dtype=np.float32)
+    o = 8
+    out = {}
+    for name, n in (("dec1", 28), ("dec2", 46), ("int1", 48), ("int2", 32), ("biquad_lowpass1", 5),
+                    ("scalars", 11), ("mask", 2 * fft_length)):
+        out[name] = f[o:o + n]
+        o += n
+    return out
+
+
+class RxChain:
+    """n_channels independent T41 receive channels resident on one MI355X."""
+
+    def __init__(self, n_channels, params=None, device=0, NCOFreq=None):
+        self._lib = _lib.load()
+        self.params = params if params is not None else default_params()
+        self._ctx = C.c_void_p()
+        check(self._lib.t41rx_create(C.byref(self._ctx), int(device), int(n_channels), C.byref(self.params)))
+        self.n_channels = int(n_channels)
+        self.device = int(device)
+        self.frame_len = self._lib.t41rx_frame_len(self._ctx)
+        if NCOFreq is not None:
+            self.SetNCOFreq(NCOFreq)
+
+    # -- configuration ---------------------------------------------------------------------
+    def CalcFilters(self, **changes):
+        """Filter/mode/gain change between two ProcessIQData() calls; state is kept."""
+        for k, v in changes.items():
+            if not hasattr(self.params, k):
+                raise AttributeError("t41rx_params has no field %r" % k)
+            setattr(self.params, k, v)
+        check(self._lib.t41rx_set_params(self._ctx, C.byref(self.params)))
+
+    SetupMode = CalcFilters
+
+    def SetNCOFreq(self, NCOFreq):
+        a = np.ascontiguousarray(np.broadcast_to(np.asarray(NCOFreq, dtype=np.int32), (self.n_channels,)))
+        check(self._lib.t41rx_set_nco_freq(self._ctx, a.ctypes.data_as(C.POINTER(C.c_int32)), self.n_channels))
+
+    def coeffs(self):
+        n = self._lib.t41rx_coeff_blob_bytes(self.params.fft_length)
+        blob = np.zeros(n, dtype=np.uint8)
+        check(self._lib.t41rx_get_coeffs(self._ctx, blob.ctypes.data_as(C.c_void_p), n))
+        return blob
+
+    def set_coeffs(self, blob):
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        check(self._lib.t41rx_set_coeffs(self._ctx, blob.ctypes.data_as(C.c_void_p), blob.size))
+
+    def reset(self):
+        check(self._lib.t41rx_reset(self._ctx))
+
+    def get_state(self):
+        n = self._lib.t41rx_state_bytes(self._ctx)
+        buf = np.zeros(n, dtype=np.uint8)
+        check(self._lib.t41rx_get_state(self._ctx, buf.ctypes.data_as(C.c_void_p), n))
+        return buf
+
+    def set_state(self, buf):
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        check(self._lib.t41rx_set_state(self._ctx, buf.ctypes.data_as(C.c_void_p), buf.size))
+
+    # -- the hot path ----------------------------------------------------------------------
+    def ProcessIQData(self, float_buffer_L, float_buffer_R, out=None):
+        """One ProcessIQData() per channel (or several consecutive ones).
+
+        torch CUDA tensors [n_channels, n_frames*frame_len] (float32, contiguous) run on the
+        current torch stream without synchronising and return a tensor; numpy arrays go
+        through the host-pointer entry point and return a numpy array.
+        """
+        if isinstance(float_buffer_L, np.ndarray):
+            I = np.ascontiguousarray(float_buffer_L, dtype=np.float32)
+            Q = np.ascontiguousarray(float_buffer_R, dtype=np.float32)
+            nfr = self._check_shape(I.shape, Q.shape)
+            audio = np.empty_like(I) if out is None else out
+            fp = C.POINTER(C.c_float)
+            check(self._lib.t41rx_process_host(self._ctx, I.ctypes.data_as(fp), Q.ctypes.data_as(fp),
+                                               audio.ctypes.data_as(fp), nfr))
+            return audio
+        import torch
+        I, Q = float_buffer_L, float_buffer_R
+        if not (I.is_cuda and Q.is_cuda and I.dtype == torch.float32 and Q.dtype == torch.float32
+                and I.is_contiguous() and Q.is_contiguous()):
+            raise ValueError("I/Q must be contiguous float32 CUDA tensors")
+        if I.device.index != self.device or Q.device.index != self.device:
+            raise ValueError("I/Q live on another device than this RxChain")
+        nfr = self._check_shape(tuple(I.shape), tuple(Q.shape))
+        audio = torch.empty_like(I) if out is None else out
+        stream = torch.cuda.current_stream(I.device).cuda_stream
+        check(self._lib.t41rx_process_device(self._ctx, I.data_ptr(), Q.data_ptr(), audio.data_ptr(), nfr,
+                                             C.c_void_p(stream)))
+        return audio
+
+    def set_debug_taps(self, post_nco=None, dec=None, demod=None):
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+        check(self._lib.t41rx_set_debug_taps(self._ctx, ptr(post_nco), ptr(dec), ptr(demod)))
+        self._taps = (post_nco, dec, demod)  # keep alive
+
+    def _check_shape(self, si, sq):
+        if si != sq or len(si) != 2 or si[0] != self.n_channels or si[1] == 0 or si[1] % self.frame_len:
+            raise ValueError("I/Q must be [n_channels=%d, k*frame_len=%d], got %r / %r"
+                             % (self.n_channels, self.frame_len, si, sq))
+        return si[1] // self.frame_len
+
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx:
+            self._lib.t41rx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

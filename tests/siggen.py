@@ -1,0 +1,52 @@
+"""Synthetic I/Q generator shared by tests and bench (SURVEY 8d "Synthetic input").
+
+Per channel: three complex tones (one placed in the demodulator's pass band after the Fs/4 and
+NCO shifts) + complex white noise, amplitudes in [0.05, 0.3], clipped to (-1, 1), 192 kS/s.
+"""
+import numpy as np
+
+FS = 192000.0
+
+
+def passband_tone_hz(mode, nco_hz, audio_hz=1000.0):
+    """input frequency that lands at +/-audio_hz after (optional I flip), +Fs/4 and -NCO"""
+    if mode == 3:  # NFM: no I sign flip (Process.cpp:165-173 skips it)
+        return -48000.0 + nco_hz + audio_hz
+    if mode == 1:  # LSB pass band is negative
+        return 48000.0 - nco_hz + audio_hz
+    return 48000.0 - nco_hz - audio_hz
+
+
+def make_iq(n_channels, n_samples, nco_hz, mode=0, seed=0x5441315F, sigma=0.01):
+    nco_hz = np.broadcast_to(np.asarray(nco_hz, dtype=np.float64), (n_channels,))
+    I = np.empty((n_channels, n_samples), dtype=np.float32)
+    Q = np.empty((n_channels, n_samples), dtype=np.float32)
+    n = np.arange(n_samples, dtype=np.float64)
+    for c in range(n_channels):
+        rng = np.random.default_rng(seed + c)
+        amps = rng.uniform(0.05, 0.3, 3)
+        freqs = rng.uniform(-90000.0, 90000.0, 3)
+        phases = rng.uniform(0, 2 * np.pi, 3)
+        freqs[0] = passband_tone_hz(mode, nco_hz[c], rng.uniform(400.0, 2500.0))
+        x = np.zeros(n_samples, dtype=np.complex128)
+        for a, f, ph in zip(amps, freqs, phases):
+            x += a * np.exp(1j * (2 * np.pi * f / FS * n + ph))
+        x += sigma * (rng.standard_normal(n_samples) + 1j * rng.standard_normal(n_samples)) / np.sqrt(2)
+        I[c] = np.clip(x.real, -0.999, 0.999)
+        Q[c] = np.clip(x.imag, -0.999, 0.999)
+    return I, Q
+
+
+def nco_grid(n_channels, seed=7):
+    """NCOFreq per channel: uniform in [-43000, 40000] Hz in 50 Hz steps (Tune.cpp:164)"""
+    rng = np.random.default_rng(seed)
+    return (rng.integers(-860, 801, n_channels) * 50).astype(np.int32)
+
+
+def block_rel_err(a, b, frame_len):
+    """per-frame max|a-b| / max|b| (SURVEY 8d tolerance definition); returns array [chan, frame]"""
+    a = np.asarray(a, dtype=np.float64).reshape(a.shape[0], -1, frame_len)
+    b = np.asarray(b, dtype=np.float64).reshape(b.shape[0], -1, frame_len)
+    den = np.abs(b).max(axis=2)
+    num = np.abs(a - b).max(axis=2)
+    return np.where(den < 1e-6, num, num / np.maximum(den, 1e-30))

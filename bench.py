@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the T41 RX hot path (batched ProcessIQData) on MI355X.
+
+One "step" = one pass of the hot path over one batch: 4096 independent channels x one
+2048-sample I/Q frame each (BASELINE.json configs[1]: batched SSB RX chain, decimate-by-8 +
+512-pt fast convolution + demod + interpolate-by-8).  Consecutive steps are consecutive frames
+of the same channels (streaming state carried in HBM).  Inputs are synthetic, generated on
+the GPU and resident in HBM before the timed region; a ring of distinct frame buffers larger
+than the 256 MiB Infinity Cache keeps the traffic on HBM.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (see the contract in the task description): whole-job
+MSamples/s (input complex samples), plus `roofline` (algorithmic 12 B/sample over the
+kernel's average launch duration from HIP events, vs 8 TB/s) and `cpu_baseline` (the CPU
+oracle timed on this host's cores on a bounded sample; N=1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import t41_sdr_amd as T  # noqa: E402
+
+FS = 192000.0
+N_CHANNELS = 4096          # BASELINE.json: batch=4096
+FFT_LENGTH = 512
+FRAME_LEN = 4 * FFT_LENGTH  # 2048 complex samples per channel per step
+BYTES_PER_SAMPLE = 12.0     # 2 x f32 in + 1 x f32 out per input complex sample
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+RING = 8                    # distinct frame buffers: 8 x 96 MiB = 768 MiB > 256 MiB Infinity Cache
+
+
+def synth_ring(n_channels, nco_hz, ring, device, seed):
+    """RING consecutive frames of SURVEY 8d's synthetic signal, built on the GPU.
+    Returns lists of [n_channels, FRAME_LEN] float32 tensors (I, Q)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    nco = torch.as_tensor(np.asarray(nco_hz, dtype=np.float64), device=device)
+    amps = 0.05 + 0.25 * torch.rand(n_channels, 3, generator=g, device=device, dtype=torch.float64)
+    freqs = -90000.0 + 180000.0 * torch.rand(n_channels, 3, generator=g, device=device, dtype=torch.float64)
+    phases = 2 * np.pi * torch.rand(n_channels, 3, generator=g, device=device, dtype=torch.float64)
+    audio = 400.0 + 2100.0 * torch.rand(n_channels, generator=g, device=device, dtype=torch.float64)
+    freqs[:, 0] = 48000.0 - nco - audio  # lands at +audio Hz in the USB pass band (I sign flip, +Fs/4, -NCO)
+    Is, Qs = [], []
+    for r in range(ring):
+        n = torch.arange(r * FRAME_LEN, (r + 1) * FRAME_LEN, device=device, dtype=torch.float64)
+        re = torch.zeros(n_channels, FRAME_LEN, device=device, dtype=torch.float64)
+        im = torch.zeros_like(re)
+        for k in range(3):
+            ph = (2 * np.pi / FS) * freqs[:, k:k + 1] * n[None, :] + phases[:, k:k + 1]
+            re += amps[:, k:k + 1] * torch.cos(ph)
+            im += amps[:, k:k + 1] * torch.sin(ph)
+        noise = torch.randn(2, n_channels, FRAME_LEN, generator=g, device=device, dtype=torch.float32)
+        Is.append((re.float() + 0.01 / np.sqrt(2) * noise[0]).clamp_(-0.999, 0.999).contiguous())
+        Qs.append((im.float() + 0.01 / np.sqrt(2) * noise[1]).clamp_(-0.999, 0.999).contiguous())
+    return Is, Qs
+
+
+def cpu_baseline(Is, Qs, nco_hz, params_kw):
+    """The CPU oracle (oracle/t41_oracle.c, a port: the reference itself is Teensy firmware)
+    on a bounded sample of the same workload, all host threads."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    nch = 1024
+    passes = 6
+    threads = max(1, min(os.cpu_count() or 1, 64))
+    I = torch.cat([t[:nch] for t in Is], dim=1).cpu().numpy()
+    Q = torch.cat([t[:nch] for t in Qs], dim=1).cpu().numpy()
+    ob = O.OracleBatch(O.default_params(**params_kw), np.asarray(nco_hz[:nch], dtype=np.int32), native=True)
+    ob.process(I[:, :FRAME_LEN], Q[:, :FRAME_LEN], nthreads=threads)  # warm caches / twiddle tables
+    t0 = time.perf_counter()
+    for _ in range(passes):
+        ob.process(I, Q, nthreads=threads)
+    dt = time.perf_counter() - t0
+    nsamp = passes * nch * I.shape[1]
+    # single-thread figure on a smaller slice
+    ob1 = O.OracleBatch(O.default_params(**params_kw), np.asarray(nco_hz[:64], dtype=np.int32), native=True)
+    t1 = time.perf_counter()
+    ob1.process(I[:64], Q[:64], nthreads=1)
+    dt1 = time.perf_counter() - t1
+    return {
+        "value": round(nsamp / dt / 1e6, 3),
+        "unit": "MSamples/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": "%d of the %d channels x %d consecutive frames (%d passes over the %d-frame ring), "
+                  "oracle/t41_oracle.c -O3 -march=native, one channel range per thread; "
+                  "1-thread rate on 64 channels x %d frames: %.3f MSamples/s"
+                  % (nch, N_CHANNELS, passes * len(Is), passes, len(Is), len(Is), 64 * I.shape[1] / dt1 / 1e6),
+    }
+
+
+def load_traffic():
+    """HBM bytes per launch from committed rocprofv3 PMC passes (profiles/), or None."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get("bytes_per_launch")
+    except Exception:
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", world_size=world, rank=rank,
+                                device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0 and world > 1:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the RX path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    params_kw = dict(mode=T.DEMOD_USB, FLoCut=200, FHiCut=3000, rfGainAllBands=1, RFgain=1,
+                     AGCMode=0, audioVolume=30)
+    params = T.default_params(**params_kw)
+    rng = np.random.default_rng(1000 + rank)
+    nco = (rng.integers(-860, 801, N_CHANNELS) * 50).astype(np.int32)  # [-43000, 40000] Hz, 50 Hz steps
+
+    rx = T.RxChain(N_CHANNELS, params, device=local_rank, NCOFreq=nco)
+    # One-shot coefficient broadcast: rank 0 designs, everyone installs (RCCL over xGMI).
+    if dist is not None:
+        blob = torch.from_numpy(rx.coeffs()).to(dev)
+        dist.broadcast(blob, src=0)
+        rx.set_coeffs(blob.cpu().numpy())
+
+    Is, Qs = synth_ring(N_CHANNELS, nco, RING, dev, seed=0x5441315F + rank)
+    outs = [torch.empty(N_CHANNELS, FRAME_LEN, device=dev, dtype=torch.float32) for _ in range(RING)]
+
+    def step(k):
+        r = k % RING
+        rx.ProcessIQData(Is[r], Qs[r], out=outs[r])
+
+    for k in range(args.warmup):
+        step(k)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()  # same stream the kernels are enqueued on (torch's current stream)
+    for k in range(args.steps):
+        step(args.warmup + k)
+    ev1.record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # average launch duration, HIP events
+    if dist is not None:
+        t = torch.tensor([wall], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+
+    if not torch.isfinite(outs[(args.warmup + args.steps - 1) % RING]).all():
+        raise SystemExit("non-finite audio output")
+
+    samples_per_step = N_CHANNELS * FRAME_LEN
+    value = world * samples_per_step * args.steps / wall / 1e6
+    achieved = BYTES_PER_SAMPLE * samples_per_step / (kernel_ms * 1e-3) / 1e9
+    line = {
+        "metric": "MSamples/s I/Q through full RX chain, batch=4096; achieved HBM GB/s vs roofline",
+        "value": round(value, 1),
+        "unit": "MSamples/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(wall / args.steps * 1e3, 5),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "configs[1]: batched SSB (USB 200-3000 Hz) RX chain, decimate-by-8 + 512-pt fast-conv + "
+                        "demod + interpolate-by-8, 4096 channels x 2048 complex f32 samples per step per GPU, "
+                        "per-channel NCO, AGC off",
+            "batch": N_CHANNELS, "frame_len": FRAME_LEN, "fft_length": FFT_LENGTH,
+            "parallelism": "channels sharded per GPU, no data-path collective",
+        },
+        "roofline": {
+            "bound": "hbm",
+            "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": load_traffic(),
+            "kernel": "rx512_kernel",
+            "kernel_ms": round(kernel_ms, 5),
+            "algorithmic_bytes_per_launch": int(BYTES_PER_SAMPLE * samples_per_step),
+        },
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(Is, Qs, nco, params_kw)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -81,6 +81,13 @@ def load():
         raise ImportError(
             "%s not found: build it with `make -C t41_sdr_amd/csrc` (or __graft_entry__.build()). "
             "There is no CPU fallback for the RX path." % LIB_PATH)
+    # PyTorch-ROCm ships its own HIP runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7).
+    # Import it first so this library binds to the SAME runtime instance that owns torch's
+    # device memory and streams; two runtimes in one process do not see each other's state.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the ABI is incomplete

@@ -1,0 +1,64 @@
+"""Generates tests/golden/*.npz: seeded inputs + the oracle's outputs for every demod mode.
+
+The reference ships no golden vectors for this path, and cannot run here, so
+these fixtures pin the ORACLE's behaviour (oracle/t41_oracle.c at the commit that generated
+them): they catch regressions of the oracle and give the GPU tests data that does not depend
+on rebuilding anything.  Re-run only when the oracle's semantics change on purpose:
+    python tests/golden/gen_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import oracle_lib as O  # noqa: E402
+import siggen  # noqa: E402
+
+CASES = {
+    # name: (params overrides, nco list)
+    "usb": (dict(mode=0, FLoCut=200, FHiCut=3000), [5000, -12350]),
+    "lsb": (dict(mode=1, FLoCut=-3000, FHiCut=-200), [-43000, 50]),
+    "am": (dict(mode=2, FLoCut=-3000, FHiCut=3000), [1000, 33300]),
+    "nfm": (dict(mode=3, FLoCut=200, FHiCut=3000), [2500, -20000]),
+    "usb_narrow_gains": (dict(mode=0, FLoCut=400, FHiCut=600, rfGainAllBands=6, RFgain=3, audioVolume=55,
+                              IQAmpCorrectionFactor=1.02, IQPhaseCorrectionFactor=-0.013), [0, 39950]),
+    "usb_cw_sidetone": (dict(mode=0, FLoCut=200, FHiCut=3000, xmtMode=1, CWFreqShift=750,
+                             IQPhaseCorrectionFactor=0.021), [650, -30000]),
+}
+NFRAMES = 3
+L = 2048
+
+
+def make_inputs(name, kw, nco):
+    nch = len(nco)
+    seed = 0x5441315F + sum(ord(c) for c in name)
+    if kw["mode"] == 3:  # FM-modulated carriers so the discriminator sees a real signal
+        rng = np.random.default_rng(seed)
+        n = np.arange(NFRAMES * L)
+        I = np.empty((nch, n.size), np.float32)
+        Q = np.empty((nch, n.size), np.float32)
+        for c in range(nch):
+            fm = rng.uniform(300, 2500)
+            dev = rng.uniform(0.5, 2.5)
+            ph = 2 * np.pi * (-48000.0 + nco[c]) / 192000.0 * n + dev * np.sin(2 * np.pi * fm / 192000.0 * n)
+            x = 0.3 * np.exp(1j * ph) + 0.003 * (rng.standard_normal(n.size) + 1j * rng.standard_normal(n.size))
+            I[c], Q[c] = x.real, x.imag
+        return I, Q
+    return siggen.make_iq(nch, NFRAMES * L, np.asarray(nco), mode=kw["mode"], seed=seed)
+
+
+def main():
+    for name, (kw, nco) in CASES.items():
+        I, Q = make_inputs(name, kw, nco)
+        p = O.default_params(**kw)
+        ob = O.OracleBatch(p, np.asarray(nco, dtype=np.int32))
+        out = ob.process(I, Q)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), I=I, Q=Q, nco=np.asarray(nco, np.int32), audio=out,
+                            params=np.array(sorted(kw.items()), dtype=object).astype(str))
+        print(name, out.shape, float(np.abs(out).max()))
+
+
+if __name__ == "__main__":
+    main()

@@ -17,7 +17,7 @@ def passband_tone_hz(mode, nco_hz, audio_hz=1000.0):
     return 48000.0 - nco_hz - audio_hz
 
 
-def make_iq(n_channels, n_samples, nco_hz, mode=0, seed=0x5441315F, sigma=0.01):
+def make_iq(n_channels, n_samples, nco_hz, mode=0, seed=0x5441315F, sigma=0.01, audio_hz=(400.0, 2500.0)):
     nco_hz = np.broadcast_to(np.asarray(nco_hz, dtype=np.float64), (n_channels,))
     I = np.empty((n_channels, n_samples), dtype=np.float32)
     Q = np.empty((n_channels, n_samples), dtype=np.float32)
@@ -27,7 +27,10 @@ def make_iq(n_channels, n_samples, nco_hz, mode=0, seed=0x5441315F, sigma=0.01):
         amps = rng.uniform(0.05, 0.3, 3)
         freqs = rng.uniform(-90000.0, 90000.0, 3)
         phases = rng.uniform(0, 2 * np.pi, 3)
-        freqs[0] = passband_tone_hz(mode, nco_hz[c], rng.uniform(400.0, 2500.0))
+        freqs[0] = passband_tone_hz(mode, nco_hz[c], rng.uniform(*audio_hz))
+        if mode == 2:  # AM: a second in-band tone gives the envelope something to demodulate
+            freqs[1] = freqs[0] + rng.uniform(300.0, 900.0)
+            amps[1] = 0.5 * amps[0]
         x = np.zeros(n_samples, dtype=np.complex128)
         for a, f, ph in zip(amps, freqs, phases):
             x += a * np.exp(1j * (2 * np.pi * f / FS * n + ph))

@@ -1,0 +1,121 @@
+"""Host logic of the product library without a GPU: every C-ABI symbol of include/t41rx.h is
+exported, the host-side coefficient designer matches the oracle's, argument checking and error
+codes behave, and creating a context without a HIP device fails loudly (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def T(built):
+    import t41_sdr_amd
+    t41_sdr_amd.load()
+    return t41_sdr_amd
+
+
+def test_every_declared_symbol_is_exported(T):
+    hdr = open(os.path.join(ROOT, "include", "t41rx.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(t41rx_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    lib = C.CDLL(T.LIB_PATH)
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, "declared in include/t41rx.h but not exported: %s" % missing
+    from t41_sdr_amd import _lib
+    assert declared == set(_lib.SYMBOLS), "python binding and header disagree"
+    assert lib.t41rx_abi_version() == 1
+
+
+def test_params_struct_layout_matches_header(T):
+    hdr = open(os.path.join(ROOT, "include", "t41rx.h")).read()
+    body = re.search(r"typedef struct t41rx_params \{(.*?)\} t41rx_params;", hdr, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = re.findall(r"(int32_t|float)\s+(\w+);", body)
+    assert [n for _, n in fields] == [n for n, _ in T.Params._fields_]
+    assert C.sizeof(T.Params) == 4 * len(fields)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(mode=0, FLoCut=200, FHiCut=3000),
+    dict(mode=1, FLoCut=-3000, FHiCut=-200),
+    dict(mode=2, FLoCut=-3000, FHiCut=3000),
+    dict(mode=3, FLoCut=200, FHiCut=3000, nfmFilterBW=12000),
+    dict(mode=0, FLoCut=400, FHiCut=600, rfGainAllBands=6, RFgain=3, audioVolume=55),
+    dict(mode=0, FLoCut=100, FHiCut=11000),  # > 10 kHz: resampler design caps at 10 kHz (Filter.cpp:408)
+    dict(mode=0, FLoCut=400, FHiCut=600, fft_length=4096),
+    dict(mode=0, FLoCut=200, FHiCut=3000, fft_length=1024),
+])
+def test_designer_matches_oracle(T, kw):
+    p = T.default_params(**kw)
+    N = p.fft_length
+    got = T.blob_fields(T.design_coeffs(p), N)
+    ref = O.coeff_arrays(O.design(O.default_params(**kw)), N)
+    for k in ("dec1", "dec2", "int1", "int2", "biquad_lowpass1"):
+        assert np.array_equal(got[k], ref[k]), k  # same f32 arithmetic -> bit-exact
+    # the mask goes through a different f32 FFT decomposition: rounding-level agreement
+    assert np.abs(got["mask"] - ref["mask"]).max() < 4e-7 * np.abs(ref["mask"]).max()
+
+
+def test_scalars_follow_process_cpp(T):
+    p = T.default_params(mode=1, FLoCut=-2800, FHiCut=-300, rfGainAllBands=4, RFgain=7, audioVolume=40,
+                         IQAmpCorrectionFactor=1.05, IQPhaseCorrectionFactor=0.02, xmtMode=1, CWFreqShift=600)
+    s = T.blob_fields(T.design_coeffs(p), 512)["scalars"]
+    assert s[0] == np.float32(10.0 ** float(np.float32(4) / np.float32(20)))       # Process.cpp:117
+    assert s[1] == 7.0 and s[2] == np.float32(-1.05) and s[3] == np.float32(0.02)  # :133, :166
+    fk = float(np.float32(2800.0 * 0.001))  # float * double -> double -> float; LSB uses -FLoCut, :485
+    assert s[4] == np.float32(7.0874 * fk ** -1.232)
+    assert s[5] == 20.0                                                             # DSP_Fn.cpp:453
+    x = np.float32(0.4)
+    assert s[6] == np.float32(8.0) * (np.float32(5) * x * x * x * x * x)            # :929, :964
+    assert s[7] == 1.0 and s[8] == 600.0                                            # LSB + CW: +CWFreqShift
+
+
+def test_design_rejects_bad_arguments(T):
+    from t41_sdr_amd import _lib
+    lib = T.load()
+    p = T.default_params()
+    n = lib.t41rx_coeff_blob_bytes(512)
+    assert n == 4 * (8 + 28 + 46 + 48 + 32 + 5 + 11 + 1024)
+    assert lib.t41rx_coeff_blob_bytes(500) == 0
+    buf = (C.c_uint8 * n)()
+    assert lib.t41rx_design_coeffs(C.byref(p), buf, n - 1) == _lib.ERR_ARG
+    assert lib.t41rx_design_coeffs(None, buf, n) == _lib.ERR_ARG
+    for bad in (dict(fft_length=300), dict(mode=9), dict(FLoCut=3000, FHiCut=200), dict(audioVolume=101),
+                dict(mode=1, FLoCut=200, FHiCut=3000), dict(FHiCut=20000)):
+        with pytest.raises(T.T41RxError) as e:
+            T.design_coeffs(T.default_params(**bad))
+        assert e.value.status == _lib.ERR_ARG
+    assert b"argument" in lib.t41rx_strerror(_lib.ERR_ARG)
+
+
+def test_no_cpu_fallback_without_a_device(T):
+    """On a box without a HIP device creating a context must fail with ERR_HIP, never silently
+    run somewhere else."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from t41_sdr_amd import _lib
+    with pytest.raises(T.T41RxError) as e:
+        T.RxChain(4)
+    assert e.value.status == _lib.ERR_HIP
+
+
+def test_product_never_touches_the_oracle():
+    """the shipped package must not import, link or open anything under oracle/"""
+    pkg = os.path.join(ROOT, "t41_sdr_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")) or f == "Makefile":
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle_lib" not in txt and "t41_oracle" not in txt and "libt41oracle" not in txt, f
+    import subprocess
+    so = os.path.join(pkg, "libt41rx.so")
+    if os.path.exists(so):
+        assert "t41oracle" not in subprocess.run(["ldd", so], capture_output=True, text=True).stdout

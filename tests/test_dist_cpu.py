@@ -1,0 +1,70 @@
+"""N>1 path on CPU: two gloo ranks shard the channels, rank 0 designs the coefficient blob and
+broadcasts it (the path's only collective), every rank ends up with the same coefficients."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_channels_partitions_exactly():
+    from t41_sdr_amd.dist import shard_channels
+    for n, w in ((4096, 8), (4096, 3), (7, 4), (1, 1), (5, 8)):
+        spans = [shard_channels(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [hi - lo for lo, hi in spans]
+        assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_channels(10, 3, 3)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    import t41_sdr_amd as T
+    from t41_sdr_amd.dist import broadcast_coeffs, max_over_ranks, shard_channels
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # rank 0 owns the "filter change"; the others start from different params
+        p = T.default_params(mode=0, FLoCut=300, FHiCut=2400) if rank == 0 else T.default_params()
+        mine = T.design_coeffs(p)
+        got = broadcast_coeffs(mine, src=0)
+        lo, hi = shard_channels(4096, rank, world)
+        t = max_over_ranks(1.0 + rank)
+        q.put((rank, got.tobytes(), lo, hi, t))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_coefficient_broadcast(built):
+    import torch.multiprocessing as mp
+    import t41_sdr_amd as T
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = T.design_coeffs(T.default_params(mode=0, FLoCut=300, FHiCut=2400)).tobytes()
+    assert res[0][1] == want and res[1][1] == want
+    assert (res[0][2], res[0][3]) == (0, 2048) and (res[1][2], res[1][3]) == (2048, 4096)
+    assert res[0][4] == 2.0 and res[1][4] == 2.0

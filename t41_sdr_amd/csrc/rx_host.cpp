@@ -133,6 +133,12 @@ int upload_coeffs(t41rx_ctx *ctx) {
     const double a = two_pi * (double)i / 256.0;
     tab[(size_t)(kTabSinCos + i)] = make_float2((float)std::cos(a), (float)std::sin(a));
   }
+  // DC high-pass (FIR.cpp:87-89, a1 = 0.854352383886757938) carry multipliers for the DPP scan
+  for (int l = 0; l < 64; ++l) {
+    const double a1 = 0.854352383886757938;
+    tab[(size_t)(kTabHp8 + l)] = make_float2((float)std::pow(a1, 8.0 * ((l & 15) + 1)), (float)std::pow(a1, 8.0 * ((l & 31) + 1)));
+    tab[(size_t)(kTabHp4 + l)] = make_float2((float)std::pow(a1, 4.0 * ((l & 15) + 1)), (float)std::pow(a1, 4.0 * ((l & 31) + 1)));
+  }
   HIP_TRY(hipMemcpy(ctx->d_tab, tab.data(), sizeof(float2) * tab.size(), hipMemcpyHostToDevice));
   return T41RX_OK;
 }

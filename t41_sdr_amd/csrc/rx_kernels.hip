@@ -150,21 +150,45 @@ constexpr double cpow(double b, int e) {
 }
 template <int n>
 struct HpTab {
-  float scanA[6];  // a1^(n * 2^s): carry multiplier across 2^s lanes
+  float scanA[4];  // a1^(n * 2^s), s = 0..3: carry multiplier across 1, 2, 4, 8 lanes
   float pw[n];     // a1^k
   constexpr HpTab() : scanA{}, pw{} {
-    for (int s = 0; s < 6; ++s) scanA[s] = (float)cpow(kHpA1, n << s);
+    for (int s = 0; s < 4; ++s) scanA[s] = (float)cpow(kHpA1, n << s);
     for (int k = 0; k < n; ++k) pw[k] = (float)cpow(kHpA1, k);
   }
 };
 
-// Runs the recurrence over `n` consecutive samples per lane (lane-major: lane l owns samples
-// l*n .. l*n+n-1), all 64 lanes in parallel: local pass with zero carry, 6-step wave scan of
-// the affine carry map (its multiplier a1^n is the same for every lane, so it folds into
-// compile-time constants), then a rank-1 fix-up.  `carry` (wave-uniform) is the filter state
-// entering lane 0 and is replaced by the state leaving lane 63.
+// GFX9 DPP controls: data moves between lanes inside the VALU, no LDS round trip
+constexpr int kDppRowShr1 = 0x111, kDppRowShr2 = 0x112, kDppRowShr4 = 0x114, kDppRowShr8 = 0x118;
+constexpr int kDppWaveShr1 = 0x138, kDppRowBcast15 = 0x142, kDppRowBcast31 = 0x143;
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ __forceinline__ float dpp_f(float old, float src) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, ROW_MASK, 0xf, BOUND));
+}
+// value of lane-1 (lane 0 gets 0)
+__device__ __forceinline__ float lane_up1(float v) { return dpp_f<kDppWaveShr1, 0xf, true>(0.0f, v); }
+
+// Inclusive wave scan of the affine carry map d_out = A d_in + B with the same A = a1^n on
+// every lane: 4 row_shr steps inside each 16-lane row, then row_bcast:15 / row_bcast:31 to
+// stitch the rows.  m15 = A^((lane&15)+1), m31 = A^((lane&31)+1) (per-lane constants).
 template <int n>
-__device__ __forceinline__ void dc_highpass(float (&x)[n], float &carry, int lane) {
+__device__ __forceinline__ float hp_scan(float B, float m15, float m31) {
+  constexpr HpTab<n> T{};
+  B = fmaf(T.scanA[0], dpp_f<kDppRowShr1, 0xf, true>(0.0f, B), B);
+  B = fmaf(T.scanA[1], dpp_f<kDppRowShr2, 0xf, true>(0.0f, B), B);
+  B = fmaf(T.scanA[2], dpp_f<kDppRowShr4, 0xf, true>(0.0f, B), B);
+  B = fmaf(T.scanA[3], dpp_f<kDppRowShr8, 0xf, true>(0.0f, B), B);
+  B = fmaf(m15, dpp_f<kDppRowBcast15, 0xa, false>(0.0f, B), B);
+  B = fmaf(m31, dpp_f<kDppRowBcast31, 0xc, false>(0.0f, B), B);
+  return B;
+}
+
+// Runs the recurrence over `n` consecutive samples per lane (lane-major: lane l owns samples
+// l*n .. l*n+n-1), all 64 lanes in parallel: local pass with zero carry, wave scan of the
+// carries, rank-1 fix-up.  `carry` (wave-uniform) is the filter state entering lane 0 and is
+// replaced by the state leaving lane 63.
+template <int n>
+__device__ __forceinline__ void dc_highpass(float (&x)[n], float &carry, int lane, float m15, float m31) {
   constexpr HpTab<n> T{};
   const float b0 = (float)kHpB0, b1 = (float)kHpB1, a1 = (float)kHpA1;
   float d = (lane == 0) ? carry : 0.0f;
@@ -174,33 +198,22 @@ __device__ __forceinline__ void dc_highpass(float (&x)[n], float &carry, int lan
     d = fmaf(a1, y, b1 * x[k]);
     x[k] = y;
   }
-  float B = d;
-#pragma unroll
-  for (int s = 0; s < 6; ++s) {
-    const float o = __shfl_up(B, 1u << s);
-    if (lane >= (1 << s)) B = fmaf(T.scanA[s], o, B);
-  }
-  float e = __shfl_up(B, 1);
-  if (lane == 0) e = 0.0f;
+  const float B = hp_scan<n>(d, m15, m31);
+  const float e = lane_up1(B);
 #pragma unroll
   for (int k = 0; k < n; ++k) x[k] = fmaf(T.pw[k], e, x[k]);
-  carry = __shfl(B, 63);
+  carry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(B), 63));
 }
 
 // filter state after `n` samples per lane when only the end state matters (zero start state)
 template <int n>
-__device__ __forceinline__ float dc_highpass_end_state(const float (&x)[n], int lane) {
-  constexpr HpTab<n> T{};
+__device__ __forceinline__ float dc_highpass_end_state(const float (&x)[n], float m15, float m31) {
   const float c = (float)(kHpB1 + kHpA1 * kHpB0), a1 = (float)kHpA1;
   float d = 0.0f;
 #pragma unroll
   for (int k = 0; k < n; ++k) d = fmaf(a1, d, c * x[k]);
-#pragma unroll
-  for (int s = 0; s < 6; ++s) {
-    const float o = __shfl_up(d, 1u << s);
-    if (lane >= (1 << s)) d = fmaf(T.scanA[s], o, d);
-  }
-  return __shfl(d, 63);
+  const float B = hp_scan<n>(d, m15, m31);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(B), 63));
 }
 
 __device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
@@ -229,6 +242,10 @@ constexpr int kY1Len = 304;
 constexpr int kY1I = 2 * kXStride, kY1Q = kY1I + kY1Len;
 constexpr int kLdsFloatsPerWave = kY1Q + kY1Len;  // 1728 floats = 6912 B
 static_assert(kLdsFloatsPerWave >= 8 * kFftRow * 2, "FFT exchange buffer must fit");
+// workgroup-shared copy of the constant tables the FFT needs (float2 units, same order as the
+// global table): mask[8][64], tw1[7][64], tw2[7][64]
+constexpr int kLdsTabFloats = 2 * kTabSinCos;  // everything before the sin/cos table
+constexpr int kLdsWaveBase = kLdsTabFloats;
 __device__ __forceinline__ int xpad(int j) { return j + ((j >> 7) << 2); }
 
 typedef const __attribute__((address_space(4))) DevCoef *CoefPtr;
@@ -323,12 +340,6 @@ __device__ __forceinline__ NcoPtr fresh_nco(NcoPtr p) {
 // ------------------------------------------------------------------------------------------
 // The fused kernel, FFT_LENGTH = 512
 // ------------------------------------------------------------------------------------------
-// One 512-sample sub-block of the front end + /4 decimator for this lane's 8 samples.
-struct FrontConst {
-  float g_rf, g_band, neg_amp, iq_phase;
-  bool iq_on;
-};
-
 template <int MODE, bool DEBUG>
 __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -336,26 +347,41 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ch = blockIdx.x * 4 + wv;
-  if (ch >= a.nchan) return;  // whole wave leaves; there are no workgroup barriers
-  float *lds = smem + wv * kLdsFloatsPerWave;
+
+  // ---- stage mask + twiddles in LDS once per workgroup (the only workgroup barrier)
+  {
+    const float4 *src = reinterpret_cast<const float4 *>(a.tab);
+    float4 *dst = reinterpret_cast<float4 *>(smem);
+#pragma unroll
+    for (int i = threadIdx.x; i < kLdsTabFloats / 4; i += 256) dst[i] = src[i];
+  }
+  // per-lane constants of the DC high-pass scan
+  const float2 hp8 = a.tab[kTabHp8 + lane];
+  const float2 hp4 = a.tab[kTabHp4 + lane];
+  __syncthreads();
+  if (ch >= a.nchan) return;  // whole wave leaves; no further workgroup barriers
+
+  const cf *ltab = reinterpret_cast<const cf *>(smem);
+  float *lds = smem + kLdsWaveBase + wv * kLdsFloatsPerWave;
   float *st = a.state + (size_t)ch * state_floats(N);
-  // coefficients are read-only for the kernel: constant address space -> scalar (SMEM) loads.
-  // fresh_coef() re-derives the pointer through an opaque asm so the compiler issues the tap
-  // loads next to their use instead of hoisting all 180 of them (and spilling SGPRs).
+  // coefficients are read-only for the kernel: constant address space -> scalar (SMEM) loads,
+  // re-derived through an opaque asm per phase so the compiler keeps the tap loads next to
+  // their use instead of hoisting all 180 of them (and spilling SGPRs).
   const CoefPtr cf0 = (CoefPtr)a.coef;
-  CoefPtr cf_ = cf0;
-  // per-channel constants are read-only for the kernel: constant address space -> scalar loads
   const NcoPtr nco = (NcoPtr)(a.nco + ch);
   const float2 *__restrict__ tab = a.tab;
 
   // per-channel NCO constants and state (wave-uniform)
   const uint64_t dphi = uniform_u64(nco->phase_inc);
-  const double r_star_sq = uniform_f64(nco->r_star_sq);
-  const double w_abs = uniform_f64(nco->w_abs);
   NcoState *ncs = reinterpret_cast<NcoState *>(st + kStNco);
   uint64_t phase0 = uniform_u64(ncs->phase);
   double osc_r = uniform_f64(ncs->r);
   float dc_carry = uniform_f32(st[kStMisc + kMiscDc]);
+  bool transient;
+  {
+    const double rs = uniform_f64(nco->r_star_sq);
+    transient = fabs(osc_r * osc_r - rs) > 1e-13;
+  }
 
   for (int f = 0; f < a.nframes; ++f) {
     const size_t fbase = ((size_t)ch * a.nframes + f) * L;
@@ -381,18 +407,31 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
       *reinterpret_cast<float4 *>(lds + kY1Q + 4 * lane) = *reinterpret_cast<const float4 *>(st + kStDec2Q + 4 * lane);
     }
 
+    // gains (Process.cpp:117-134, 165-166).  g_band and -IQAmp are folded into one factor on I
+    // (exact whenever either is +-1, which is the firmware default; one rounding otherwise)
+    float g_rf, g_i, g_q, iq_phase;
+    {
+      const CoefPtr c = fresh_coef(cf0);
+      g_rf = c->sc[kScRfGain];
+      const float gb = c->sc[kScBandGain];
+      const bool iq_on = c->sc[kScIqCorrOn] != 0.0f;
+      g_i = iq_on ? gb * c->sc[kScNegIqAmp] : gb;
+      g_q = gb;
+      iq_phase = iq_on ? c->sc[kScIqPhase] : 0.0f;
+    }
+
     // ---- Q's DC-block start state = state after ALL of this frame's I (one shared biquad
     // instance runs over I then Q, Process.cpp:127-128).  a1^256 ~ 3e-18, so the last 256 I
     // samples decide it.
     float dc_carry_i = dc_carry;
     float dc_carry_q;
     {
-      const float g_rf = fresh_coef(cf0)->sc[kScRfGain];
       const float x[4] = {tailI.x * g_rf, tailI.y * g_rf, tailI.z * g_rf, tailI.w * g_rf};
-      dc_carry_q = dc_highpass_end_state<4>(x, lane);
+      dc_carry_q = dc_highpass_end_state<4>(x, hp4.x, hp4.y);
     }
 
     float y2I[2][2], y2Q[2][2];  // /8 outputs of this frame: m = 128*round + 2*lane + e
+    cf v[8];                     // FFT registers; v[0..3] = previous block, prefetched below
 
 #pragma unroll
     for (int rd = 0; rd < 2; ++rd) {
@@ -407,46 +446,50 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
           nI1 = *reinterpret_cast<const float4 *>(gI + o + 4);
           nQ0 = *reinterpret_cast<const float4 *>(gQ + o);
           nQ1 = *reinterpret_cast<const float4 *>(gQ + o + 4);
+        } else {  // last sub-block: prefetch the overlap-save "previous" block instead
+          const float2 *ov = reinterpret_cast<const float2 *>(st + kStOverlap);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float2 t = ov[64 * j + lane];
+            v[j] = cf{t.x, t.y};
+          }
         }
-        // -- RF gain (Process.cpp:117-119), DC high-pass (127-128), band gain (133-134)
-        cf_ = fresh_coef(cf0);
-        const float g_rf = cf_->sc[kScRfGain], g_band = cf_->sc[kScBandGain];
-        const float neg_amp = cf_->sc[kScNegIqAmp], iq_phase = cf_->sc[kScIqPhase];
-        const bool iq_on = cf_->sc[kScIqCorrOn] != 0.0f;
+        // -- RF gain, DC high-pass, band gain / IQ amplitude
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           xi[k] *= g_rf;
           xq[k] *= g_rf;
         }
-        dc_highpass<8>(xi, dc_carry_i, lane);
-        dc_highpass<8>(xq, dc_carry_q, lane);
+        dc_highpass<8>(xi, dc_carry_i, lane, hp8.x, hp8.y);
+        dc_highpass<8>(xq, dc_carry_q, lane, hp8.x, hp8.y);
+        if (g_i != 1.0f) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          xi[k] *= g_band;
-          xq[k] *= g_band;
+          for (int k = 0; k < 8; ++k) xi[k] *= g_i;
         }
-        // -- IQ amplitude / phase correction (Process.cpp:165-173, Utility.cpp:178-187)
-        if (iq_on) {
+        if (g_q != 1.0f) {
 #pragma unroll
-          for (int k = 0; k < 8; ++k) xi[k] *= neg_amp;
-          if (iq_phase < 0.0f) {
+          for (int k = 0; k < 8; ++k) xq[k] *= g_q;
+        }
+        // -- IQ phase correction (Utility.cpp:178-187)
+        if (iq_phase < 0.0f) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) xq[k] = fmaf(iq_phase, xi[k], xq[k]);
-          } else if (iq_phase > 0.0f) {
+          for (int k = 0; k < 8; ++k) xq[k] = fmaf(iq_phase, xi[k], xq[k]);
+        } else if (iq_phase > 0.0f) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) xi[k] = fmaf(iq_phase, xq[k], xi[k]);
-          }
+          for (int k = 0; k < 8; ++k) xi[k] = fmaf(iq_phase, xq[k], xi[k]);
         }
         // -- oscillator for my 8 samples.  Osc_n = V_n * W has phase phase0 + (n+1) dphi.
         const int n0 = 512 * s + 8 * lane;
         float amp[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) amp[k] = 1.0f;
-        const bool transient = fabs(osc_r * osc_r - r_star_sq) > 1e-13;
         if (transient) {
           // start-up of the amplitude loop g = 1.95 - |V|^2 (Freq_Shift.cpp:130-134): replay the
           // scalar recurrence (wave-uniform); each lane keeps its own 8 values.  |Osc_n| / A* =
           // |V_n| / r*.
+          const NcoPtr nt = fresh_nco(nco);
+          const double r_star_sq = uniform_f64(nt->r_star_sq);
+          const double w_abs = uniform_f64(nt->w_abs);
           const double inv_r = 1.0 / sqrt(r_star_sq);
           double r = osc_r;
           for (int g = 0; g < 64; ++g) {
@@ -492,6 +535,10 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
           mi[k] = fmaf(ex_i, osc.x, ex_q * osc.y);
           mq[k] = fmaf(ex_q, osc.x, -(ex_i * osc.y));
         }
+        if (transient) {
+          const double rs = uniform_f64(fresh_nco(nco)->r_star_sq);
+          transient = fabs(osc_r * osc_r - rs) > 1e-13;
+        }
         if (DEBUG && a.dbg_nco) {
           float *dn = a.dbg_nco + ((size_t)ch * a.nframes + f) * (2 * L);
 #pragma unroll
@@ -513,12 +560,10 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
         float o1[2][2];  // [I/Q][e]
         // arm_fir_decimate_f32: y[m] = sum_i c[i] * state[4m + i]; state[i] = buf[i + 1]
         {
-          auto px = [](int j) { return j; };  // offsets inside a lane window never cross a pad
           const int wbase = xpad(8 * lane);
           // a lane's 36-float window [8 lane, 8 lane + 36) can cross one 128-float pad
           // boundary: use the exact padded index per float4
           auto pidx = [&](int o) { return xpad(8 * lane + o) - wbase; };
-          (void)px;
           fir_pair<kDec1Taps, 1, 5, 9, 5>(lds + kXI + wbase, pidx, (CFloatPtr)cf0->dec1, o1[0][0], o1[0][1]);
           wave_sync();
           fir_pair<kDec1Taps, 1, 5, 9, 5>(lds + kXQ + wbase, pidx, (CFloatPtr)cf0->dec1, o1[1][0], o1[1][1]);
@@ -565,7 +610,8 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
     phase0 += (uint64_t)L * dphi;
     dc_carry = dc_carry_q;  // the shared biquad ends the frame on Q
 
-    // ---- delay lines back to HBM (the LDS copies are about to be reused as scratch)
+    // ---- delay lines back to HBM (the LDS copies are about to be reused as scratch); issue
+    // the small back-end history loads now so the FFT hides their latency
     wave_sync();
     if (lane < 7) {
       *reinterpret_cast<float4 *>(st + kStDec1I + 4 * lane) = lds4(lds + kXI + 4 * lane);
@@ -575,6 +621,10 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
       *reinterpret_cast<float4 *>(st + kStDec2I + 4 * lane) = lds4(lds + kY1I + 4 * lane);
       *reinterpret_cast<float4 *>(st + kStDec2Q + 4 * lane) = lds4(lds + kY1Q + 4 * lane);
     }
+    float4 hist1 = make_float4(0, 0, 0, 0);
+    if (lane < 6) hist1 = *reinterpret_cast<const float4 *>(st + kStInt1 + 4 * lane);
+    float hist2 = 0.0f;
+    if (lane < 8) hist2 = st[kStInt2 + lane];
     wave_sync();
 
     // ---- level adjust (Process.cpp:481-492)
@@ -598,7 +648,6 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
     }
 
     // ---- overlap-save assemble (Process.cpp:498-522): v[0..3] = previous block, v[4..7] = new
-    cf v[8];
     {
       cf *tb = reinterpret_cast<cf *>(lds);
 #pragma unroll
@@ -610,11 +659,6 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
       for (int j = 0; j < 4; ++j) v[4 + j] = tb[lane + 64 * j];
       float2 *ov = reinterpret_cast<float2 *>(st + kStOverlap);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float2 t = ov[64 * j + lane];
-        v[j] = cf{t.x, t.y};
-      }
-#pragma unroll
       for (int j = 0; j < 4; ++j) ov[64 * j + lane] = make_float2(v[4 + j].x, v[4 + j].y);
     }
 
@@ -623,17 +667,12 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
       cf tw1[7], tw2[7];
 #pragma unroll
       for (int q = 0; q < 7; ++q) {
-        const float2 t1 = tab[kTabTw1 + 64 * q + lane];
-        const float2 t2 = tab[kTabTw2 + 64 * q + lane];
-        tw1[q] = cf{t1.x, t1.y};
-        tw2[q] = cf{t2.x, t2.y};
+        tw1[q] = ltab[kTabTw1 + 64 * q + lane];
+        tw2[q] = ltab[kTabTw2 + 64 * q + lane];
       }
       fft512<false>(v, tw1, tw2, lds, lane);
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const float2 m = tab[kTabMask + 64 * r + lane];
-        v[r] = cmul(v[r], cf{m.x, m.y});
-      }
+      for (int r = 0; r < 8; ++r) v[r] = cmul(v[r], ltab[kTabMask + 64 * r + lane]);
       fft512<true>(v, tw1, tw2, lds, lane);
     }
 
@@ -652,8 +691,7 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
     // LDS buf: [0] pad, [1..23] history, [24 + i] new sample i
     wave_sync();
     {
-      if (lane < 6)
-        *reinterpret_cast<float4 *>(lds + 4 * lane) = *reinterpret_cast<const float4 *>(st + kStInt1 + 4 * lane);
+      if (lane < 6) *reinterpret_cast<float4 *>(lds + 4 * lane) = hist1;
 #pragma unroll
       for (int j = 0; j < 4; ++j) lds[24 + lane + 64 * j] = aud[j];
     }
@@ -695,13 +733,11 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
       const float out_scale = fresh_coef(cf0)->sc[kScOutScale];
       float c4[32];
       load_taps<32>(c4, (CFloatPtr)cf0->int2);
-      const float4 h0 = *reinterpret_cast<const float4 *>(st + kStInt2);
-      const float4 h1 = *reinterpret_cast<const float4 *>(st + kStInt2 + 4);
-      const float hs[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
 #pragma unroll
       for (int i = 0; i < 7; ++i) {
-        const float up = __shfl_up(u1[i + 1], 1);
-        w[i] = (lane == 0) ? hs[i + 1] : up;
+        const float up = lane_up1(u1[i + 1]);
+        const float h = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hist2), i + 1));
+        w[i] = (lane == 0) ? h : up;
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) w[7 + i] = u1[i];
@@ -742,7 +778,7 @@ static hipError_t launch512(const RxArgs &a, hipStream_t s, bool debug) {
   // 40 KiB of dynamic LDS per workgroup pins residency at exactly 4 workgroups (16 waves)
   // per CU, so a 4096-channel batch is one full, balanced wave of work on 256 CUs.
   const size_t lds = 40960;
-  static_assert(4 * kLdsFloatsPerWave * sizeof(float) <= 40960, "LDS slice too large");
+  static_assert((kLdsTabFloats + 4 * kLdsFloatsPerWave) * sizeof(float) <= 40960, "LDS slice too large");
   if (debug)
     hipLaunchKernelGGL((rx512_kernel<MODE, true>), dim3(grid), dim3(256), lds, s, a);
   else

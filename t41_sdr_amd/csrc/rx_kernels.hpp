@@ -11,11 +11,14 @@ namespace t41 {
 //   tw1   [7][64] : W512^(lane * q),        q = 1..7   (forward sign)
 //   tw2   [7][64] : W64^((lane & 7) * q),   q = 1..7
 //   sincos[256]   : (cos, sin)(2 pi i / 256)
+//   hp8[64], hp4[64]: DC high-pass scan multipliers (a1^(n((l&15)+1)), a1^(n((l&31)+1))), n = 8, 4
 constexpr int kTabMask = 0;
 constexpr int kTabTw1 = 512;
 constexpr int kTabTw2 = kTabTw1 + 7 * 64;
 constexpr int kTabSinCos = kTabTw2 + 7 * 64;
-constexpr int kTabEntries512 = kTabSinCos + 256;
+constexpr int kTabHp8 = kTabSinCos + 256;
+constexpr int kTabHp4 = kTabHp8 + 64;
+constexpr int kTabEntries512 = kTabHp4 + 64;
 
 struct RxArgs {
   const float *__restrict__ I;

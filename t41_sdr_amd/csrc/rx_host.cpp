@@ -85,8 +85,18 @@ ChanNco make_nco(int32_t nco_freq_hz, int side_tone_hz) {
   n.r_star_sq = 1.95 - 1.0 / n.w_abs;
   const double amp = (double)1.1f * std::sqrt(n.r_star_sq) * n.w_abs;  // freqAdjFactor * |Osc|
   for (int k = 0; k < 8; ++k) {
-    n.wk[k][0] = (float)(amp * (double)cosl(ang * k));
-    n.wk[k][1] = (float)(amp * (double)sinl(ang * k));
+    // 1.1 A e^{j k ang} (-j)^k: the (-j)^k folds FreqShift1's x j^n (Freq_Shift.cpp:42-65) into the
+    // conjugate multiply of the mixer; a rotation by k quarter turns is exact
+    const double c = amp * (double)cosl(ang * k), s = amp * (double)sinl(ang * k);
+    double re, im;
+    switch (k & 3) {
+      case 0: re = c; im = s; break;
+      case 1: re = s; im = -c; break;   // (c + js)(-j) = s - jc
+      case 2: re = -c; im = -s; break;
+      default: re = -s; im = c; break;  // (c + js)(j) = -s + jc
+    }
+    n.wk[k][0] = (float)re;
+    n.wk[k][1] = (float)im;
   }
   return n;
 }

@@ -78,10 +78,8 @@ static_assert(sizeof(ChanNco) == 8 + 64 + 16, "ChanNco layout");
 // ---- per-channel streaming state in HBM (floats), one contiguous record per channel ----
 // Offsets in floats; every section 16-byte aligned.  "pad" entries keep the delay lines
 // float4-aligned with the newest history sample adjacent to the first new sample.
-constexpr int kStDec1I = 0;     // 28: [0] pad, [1..27] = last 27 post-NCO I samples
-constexpr int kStDec1Q = 28;    // 28
-constexpr int kStDec2I = 56;    // 48: [0..2] pad, [3..47] = last 45 dec1 outputs
-constexpr int kStDec2Q = 104;   // 48
+constexpr int kStDec1 = 0;      // 28 complex (I,Q interleaved): [0] pad, [1..27] = last 27 post-NCO samples
+constexpr int kStDec2 = 56;     // 48 complex: [0..2] pad, [3..47] = last 45 /4-decimator outputs
 constexpr int kStInt1 = 152;    // 24: [0] pad, [1..23] = last 23 demodulated samples
 constexpr int kStInt2 = 176;    // 8:  [0] pad, [1..7]  = last 7 int1 outputs
 constexpr int kStMisc = 184;    // 16 floats: see below

@@ -25,6 +25,14 @@
 //   volume                        Process.cpp:929
 //
 // No MFMA: FIR taps and FFT butterflies are not dense contractions (BASELINE north_star).
+//
+// Arithmetic is packed FP32 throughout: measured on MI355X (tools/ubench/valu_rate.hip) a
+// wave64 v_fma_f32 and a v_pk_fma_f32 both issue once per ~4 cycles per SIMD, so the packed
+// form does twice the work per issue slot (72 vs 140 TFLOP/s).  Every stage therefore works on
+// (I, Q) / (re, im) / (even, odd) register pairs: one v_pk_fma_f32 per complex FIR tap with the
+// tap broadcast from an SGPR via op_sel, two packed instructions per complex multiply
+// (op_sel / neg modifiers, inline asm because hipcc does not fold the swizzles), and
+// one per complex add or +-j rotation.
 #include <hip/hip_runtime.h>
 
 #include "rx_internal.hpp"
@@ -45,50 +53,71 @@ __device__ __forceinline__ void wave_sync() {
   asm volatile("" ::: "memory");
 }
 
-struct alignas(8) cf {
-  float x, y;
-};
-__device__ __forceinline__ cf cmul(cf a, cf b) {
-  return cf{fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x)};
-}
-__device__ __forceinline__ cf cmulc(cf a, cf b) {  // a * conj(b)
-  return cf{fmaf(a.x, b.x, a.y * b.y), fmaf(a.y, b.x, -(a.x * b.y))};
-}
-__device__ __forceinline__ cf cadd(cf a, cf b) { return cf{a.x + b.x, a.y + b.y}; }
-__device__ __forceinline__ cf csub(cf a, cf b) { return cf{a.x - b.x, a.y - b.y}; }
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef f2 cf;  // .x = re / I, .y = im / Q, one even-aligned VGPR pair
 
-// 8-point DFT in registers, natural order in and out.  INV selects e^{+j...}.
+__device__ __forceinline__ f2 splat(float s) { return f2{s, s}; }
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// complex a*b: (ax bx - ay by, ax by + ay bx) in two packed instructions
+__device__ __forceinline__ cf cmul(cf a, cf b) {
+  cf t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(t) : "v"(a), "v"(b));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+  return r;
+}
+// complex a*conj(b): (ax bx + ay by, ay bx - ax by)
+__device__ __forceinline__ cf cmulc(cf a, cf b) {
+  cf t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(b));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+  return r;
+}
+// same as cmul with b wave-uniform in an SGPR pair
+__device__ __forceinline__ cf cmul_s(cf a, cf b_uniform) {
+  cf t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(t) : "v"(a), "s"(b_uniform));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(a), "s"(b_uniform), "v"(t));
+  return r;
+}
+// a + (-j) b = (ax + by, ay - bx)   and   a + j b = (ax - by, ay + bx)
+__device__ __forceinline__ cf add_mj(cf a, cf b) {
+  cf r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ cf add_pj(cf a, cf b) {
+  cf r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+// 8-point DFT in registers, natural order in and out.  INV selects e^{+j...}.  26 packed ops.
 template <bool INV>
 __device__ __forceinline__ void dft8(cf (&v)[8]) {
   constexpr float kR = 0.70710678118654752440f;
-  const cf a0 = cadd(v[0], v[4]), a1 = csub(v[0], v[4]);
-  const cf a2 = cadd(v[2], v[6]), a3 = csub(v[2], v[6]);
-  const cf a4 = cadd(v[1], v[5]), a5 = csub(v[1], v[5]);
-  const cf a6 = cadd(v[3], v[7]), a7 = csub(v[3], v[7]);
-  const cf b0 = cadd(a0, a2), b1 = csub(a0, a2);
-  const cf b2 = cadd(a4, a6), b3 = csub(a4, a6);
-  // multiply by -j (forward) / +j (inverse)
-  auto rot = [](cf z) { return INV ? cf{-z.y, z.x} : cf{z.y, -z.x}; };
-  const cf ja3 = rot(a3), ja7 = rot(a7), jb3 = rot(b3);
-  const cf c0 = cadd(a1, ja3), c1 = csub(a1, ja3);
-  const cf d0 = cadd(a5, ja7), d1 = csub(a5, ja7);
-  // W8^1 * d0 and W8^3 * d1
-  cf e0, e1;
-  if (!INV) {
-    e0 = cf{(d0.x + d0.y) * kR, (d0.y - d0.x) * kR};
-    e1 = cf{(d1.y - d1.x) * kR, -(d1.x + d1.y) * kR};
-  } else {
-    e0 = cf{(d0.x - d0.y) * kR, (d0.x + d0.y) * kR};
-    e1 = cf{-(d1.x + d1.y) * kR, (d1.x - d1.y) * kR};
-  }
-  v[0] = cadd(b0, b2);
-  v[4] = csub(b0, b2);
-  v[2] = cadd(b1, jb3);
-  v[6] = csub(b1, jb3);
-  v[1] = cadd(c0, e0);
-  v[5] = csub(c0, e0);
-  v[3] = cadd(c1, e1);
-  v[7] = csub(c1, e1);
+  const cf a0 = v[0] + v[4], a1 = v[0] - v[4];
+  const cf a2 = v[2] + v[6], a3 = v[2] - v[6];
+  const cf a4 = v[1] + v[5], a5 = v[1] - v[5];
+  const cf a6 = v[3] + v[7], a7 = v[3] - v[7];
+  const cf b0 = a0 + a2, b1 = a0 - a2;
+  const cf b2 = a4 + a6, b3 = a4 - a6;
+  // forward: W4 = -j, W8 = (1-j)/sqrt2, W8^3 = (-1-j)/sqrt2; inverse: conjugates
+  const cf c0 = INV ? add_pj(a1, a3) : add_mj(a1, a3);
+  const cf c1 = INV ? add_mj(a1, a3) : add_pj(a1, a3);
+  const cf d0 = INV ? add_pj(a5, a7) : add_mj(a5, a7);
+  const cf d1 = INV ? add_mj(a5, a7) : add_pj(a5, a7);
+  // W8 d0 = kR (d0 + (-j) d0) fwd / kR (d0 + j d0) inv;  W8^3 d1 = -kR (d1 + j d1) fwd / -kR (d1 + (-j) d1) inv
+  const cf t0 = INV ? add_pj(d0, d0) : add_mj(d0, d0);
+  const cf t1 = INV ? add_mj(d1, d1) : add_pj(d1, d1);
+  v[0] = b0 + b2;
+  v[4] = b0 - b2;
+  v[2] = INV ? add_pj(b1, b3) : add_mj(b1, b3);
+  v[6] = INV ? add_mj(b1, b3) : add_pj(b1, b3);
+  v[1] = pk_fma(t0, splat(kR), c0);
+  v[5] = pk_fma(t0, splat(-kR), c0);
+  v[3] = pk_fma(t1, splat(-kR), c1);
+  v[7] = pk_fma(t1, splat(kR), c1);
 }
 
 // LDS exchange buffer row stride for the FFT transposes (in complex elements): 64 + 8 keeps
@@ -165,44 +194,50 @@ template <int CTRL, int ROW_MASK, bool BOUND>
 __device__ __forceinline__ float dpp_f(float old, float src) {
   return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, ROW_MASK, 0xf, BOUND));
 }
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ __forceinline__ f2 dpp_f2(f2 src) {
+  return f2{dpp_f<CTRL, ROW_MASK, BOUND>(0.0f, src.x), dpp_f<CTRL, ROW_MASK, BOUND>(0.0f, src.y)};
+}
 // value of lane-1 (lane 0 gets 0)
 __device__ __forceinline__ float lane_up1(float v) { return dpp_f<kDppWaveShr1, 0xf, true>(0.0f, v); }
 
 // Inclusive wave scan of the affine carry map d_out = A d_in + B with the same A = a1^n on
 // every lane: 4 row_shr steps inside each 16-lane row, then row_bcast:15 / row_bcast:31 to
 // stitch the rows.  m15 = A^((lane&15)+1), m31 = A^((lane&31)+1) (per-lane constants).
+// Works on an (I, Q) pair of chains at once.
 template <int n>
-__device__ __forceinline__ float hp_scan(float B, float m15, float m31) {
+__device__ __forceinline__ f2 hp_scan(f2 B, float m15, float m31) {
   constexpr HpTab<n> T{};
-  B = fmaf(T.scanA[0], dpp_f<kDppRowShr1, 0xf, true>(0.0f, B), B);
-  B = fmaf(T.scanA[1], dpp_f<kDppRowShr2, 0xf, true>(0.0f, B), B);
-  B = fmaf(T.scanA[2], dpp_f<kDppRowShr4, 0xf, true>(0.0f, B), B);
-  B = fmaf(T.scanA[3], dpp_f<kDppRowShr8, 0xf, true>(0.0f, B), B);
-  B = fmaf(m15, dpp_f<kDppRowBcast15, 0xa, false>(0.0f, B), B);
-  B = fmaf(m31, dpp_f<kDppRowBcast31, 0xc, false>(0.0f, B), B);
+  B = pk_fma(splat(T.scanA[0]), dpp_f2<kDppRowShr1, 0xf, true>(B), B);
+  B = pk_fma(splat(T.scanA[1]), dpp_f2<kDppRowShr2, 0xf, true>(B), B);
+  B = pk_fma(splat(T.scanA[2]), dpp_f2<kDppRowShr4, 0xf, true>(B), B);
+  B = pk_fma(splat(T.scanA[3]), dpp_f2<kDppRowShr8, 0xf, true>(B), B);
+  B = pk_fma(splat(m15), dpp_f2<kDppRowBcast15, 0xa, false>(B), B);
+  B = pk_fma(splat(m31), dpp_f2<kDppRowBcast31, 0xc, false>(B), B);
   return B;
 }
 
-// Runs the recurrence over `n` consecutive samples per lane (lane-major: lane l owns samples
-// l*n .. l*n+n-1), all 64 lanes in parallel: local pass with zero carry, wave scan of the
-// carries, rank-1 fix-up.  `carry` (wave-uniform) is the filter state entering lane 0 and is
-// replaced by the state leaving lane 63.
+// Runs the recurrence over `n` consecutive (I, Q) samples per lane (lane-major: lane l owns
+// samples l*n .. l*n+n-1), all 64 lanes in parallel: local pass with zero carry, wave scan of
+// the carries, rank-1 fix-up.  `carry` (wave-uniform pair) is the filter state entering lane 0
+// for the I chain and the Q chain and is replaced by the state leaving lane 63.
 template <int n>
-__device__ __forceinline__ void dc_highpass(float (&x)[n], float &carry, int lane, float m15, float m31) {
+__device__ __forceinline__ void dc_highpass(f2 (&x)[n], f2 &carry, int lane, float m15, float m31) {
   constexpr HpTab<n> T{};
   const float b0 = (float)kHpB0, b1 = (float)kHpB1, a1 = (float)kHpA1;
-  float d = (lane == 0) ? carry : 0.0f;
+  f2 d = (lane == 0) ? carry : splat(0.0f);
 #pragma unroll
   for (int k = 0; k < n; ++k) {
-    const float y = fmaf(b0, x[k], d);
-    d = fmaf(a1, y, b1 * x[k]);
+    const f2 y = pk_fma(splat(b0), x[k], d);
+    d = pk_fma(splat(a1), y, splat(b1) * x[k]);
     x[k] = y;
   }
-  const float B = hp_scan<n>(d, m15, m31);
-  const float e = lane_up1(B);
+  const f2 B = hp_scan<n>(d, m15, m31);
+  const f2 e = f2{lane_up1(B.x), lane_up1(B.y)};
 #pragma unroll
-  for (int k = 0; k < n; ++k) x[k] = fmaf(T.pw[k], e, x[k]);
-  carry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(B), 63));
+  for (int k = 0; k < n; ++k) x[k] = pk_fma(splat(T.pw[k]), e, x[k]);
+  carry = f2{__int_as_float(__builtin_amdgcn_readlane(__float_as_int(B.x), 63)),
+             __int_as_float(__builtin_amdgcn_readlane(__float_as_int(B.y), 63))};
 }
 
 // filter state after `n` samples per lane when only the end state matters (zero start state)
@@ -212,8 +247,8 @@ __device__ __forceinline__ float dc_highpass_end_state(const float (&x)[n], floa
   float d = 0.0f;
 #pragma unroll
   for (int k = 0; k < n; ++k) d = fmaf(a1, d, c * x[k]);
-  const float B = hp_scan<n>(d, m15, m31);
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(B), 63));
+  const f2 B = hp_scan<n>(f2{d, 0.0f}, m15, m31);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(B.x), 63));
 }
 
 __device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
@@ -229,24 +264,28 @@ __device__ __forceinline__ float uniform_f32(float v) {
 }
 
 // ------------------------------------------------------------------------------------------
-// LDS layout of one wave (floats)
+// LDS layout (floats).  Workgroup: [tables | wave 0 | wave 1 | wave 2 | wave 3]
 // ------------------------------------------------------------------------------------------
-// X  : post-NCO samples of one 512-sample sub-block + 28-entry history, I and Q.
-//      logical index j: [0] pad, [1..27] history, [28+k] new sample k.  4 floats of padding
-//      every 128 keep the 32-byte-strided ds_read_b128 of the /4 decimator conflict-free.
-// Y1 : /4 decimator outputs of two sub-blocks (256) + 48-entry history, I and Q.
-//      logical j: [0..2] pad, [3..47] history, [48+m] new.
-constexpr int kXStride = 560;
-constexpr int kXI = 0, kXQ = kXStride;
-constexpr int kY1Len = 304;
-constexpr int kY1I = 2 * kXStride, kY1Q = kY1I + kY1Len;
-constexpr int kLdsFloatsPerWave = kY1Q + kY1Len;  // 1728 floats = 6912 B
-static_assert(kLdsFloatsPerWave >= 8 * kFftRow * 2, "FFT exchange buffer must fit");
-// workgroup-shared copy of the constant tables the FFT needs (float2 units, same order as the
-// global table): mask[8][64], tw1[7][64], tw2[7][64]
-constexpr int kLdsTabFloats = 2 * kTabSinCos;  // everything before the sin/cos table
-constexpr int kLdsWaveBase = kLdsTabFloats;
-__device__ __forceinline__ int xpad(int j) { return j + ((j >> 7) << 2); }
+// tables: mask[8][64], tw1[7][64] as in the constant table, tw2 compacted to [7][8] (float2 each).
+// Per wave, everything is interleaved complex (I, Q):
+// X  : post-NCO samples of one 512-sample sub-block + 28-entry history.
+//      logical complex index j: [0] pad, [1..27] history, [28+k] new sample k.  One 16-byte
+//      slot of padding after every 8 complex = after every lane's share, so (a) the lane stride
+//      is 5 slots and the ds_read_b128 windows of the /4 decimator are bank-conflict-free
+//      (5 is odd: any 16 lanes distinct mod 16 hit 16 distinct slots) and (b) every lane sees
+//      the pads at the same offsets of its window, i.e. all LDS offsets are immediates.
+//      Doubles as FFT exchange / transposition scratch.
+// Y1 : /4 decimator outputs of two sub-blocks (256) + 48-entry history, unpadded
+//      (lane stride 2 slots: 2-way conflicts on 52 reads per frame, cheaper than the LDS a
+//      per-lane pad would cost).  logical j: [0..2] pad, [3..47] history, [48+m] new.
+constexpr int kLdsTabMask = 0, kLdsTabTw1 = 512, kLdsTabTw2 = 512 + 448;  // float2 units
+constexpr int kLdsTabFloats = 2 * (512 + 448 + 56);                          // 2032 floats
+constexpr int kXFloats = 1352;  // 2 * (xpad(539) + 1) = 1348, rounded to 16 B
+constexpr int kY1Floats = 608;  // 304 complex
+constexpr int kX = 0, kY1 = kXFloats;
+constexpr int kLdsFloatsPerWave = kXFloats + kY1Floats;  // 1960 floats = 7840 B
+static_assert(kXFloats >= 8 * kFftRow * 2, "FFT exchange buffer must fit in X");
+__device__ __forceinline__ constexpr int xpad(int j) { return j + ((j >> 3) << 1); }  // complex units
 
 typedef const __attribute__((address_space(4))) DevCoef *CoefPtr;
 __device__ __forceinline__ CoefPtr fresh_coef(CoefPtr p) {
@@ -288,33 +327,28 @@ __device__ __forceinline__ void load_taps(float (&dst)[N], CFloatPtr p) {
   }
 }
 
-
-// Two adjacent outputs of a decimating FIR from one lane-contiguous LDS window:
+// Two adjacent complex outputs of a decimating FIR from one lane-contiguous LDS window:
 //   acc0 = sum_i c[i] * w[OFF0 + i],  acc1 = sum_i c[i] * w[OFF1 + i],  i = 0..NT-1 in order
-// (arm_fir_decimate_f32's tap order), where w[] is NLOAD float4 reads starting at `win`
-// (IDX maps the logical float index of each float4 to its padded LDS position).
-// The window is streamed: every value is consumed right after its ds_read_b128, taps arrive in
-// 8-wide scalar-load chunks just before first use, and a wave-scope fence every GROUP loads
-// keeps the compiler from hoisting the whole window into registers.
+// (arm_fir_decimate_f32's tap order; I and Q share the taps, so each MAC is ONE v_pk_fma_f32
+// with the tap broadcast from an SGPR).  w[] is NLOAD ds_read_b128 (2 complex each) starting at
+// `win`; IDX maps a logical complex offset to its padded LDS offset.  The window is streamed:
+// values are consumed right after their load, taps arrive in 8-wide scalar-load chunks just
+// before first use, and the accumulators are pinned every GROUP loads so the compiler cannot
+// hoist the whole window into registers.
 template <int NT, int OFF0, int OFF1, int NLOAD, int GROUP, typename IDX>
-__device__ __forceinline__ void fir_pair(const float *win, IDX idx, CFloatPtr taps, float &acc0,
-                                         float &acc1) {
+__device__ __forceinline__ void fir_pair(const float *win, IDX idx, CFloatPtr taps, cf &acc0, cf &acc1) {
   constexpr int NTP = (NT + 7) & ~7;
   float tc[NTP];
-  acc0 = 0.0f;
-  acc1 = 0.0f;
+  acc0 = splat(0.0f);
+  acc1 = splat(0.0f);
 #pragma unroll
   for (int l = 0; l < NLOAD; ++l) {
-    if (l > 0 && (l % GROUP) == 0) {
-      // tie the accumulators to the instruction order: everything issued so far is consumed
-      // before the next group of loads is issued (bounded live ranges)
-      asm volatile("" : "+v"(acc0), "+v"(acc1)::"memory");
-    }
-    const float4 t = lds4(win + idx(4 * l));
-    const float tv[4] = {t.x, t.y, t.z, t.w};
+    if (l > 0 && (l % GROUP) == 0) asm volatile("" : "+v"(acc0), "+v"(acc1)::"memory");
+    const float4 t = lds4(win + 2 * idx(2 * l));
+    const cf tv[2] = {cf{t.x, t.y}, cf{t.z, t.w}};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int x = 4 * l + j;
+    for (int j = 0; j < 2; ++j) {
+      const int x = 2 * l + j;
       const int i0 = x - OFF0, i1 = x - OFF1;
       if (i0 >= 0 && i0 < NT) {
         if ((i0 & 7) == 0) {
@@ -323,9 +357,9 @@ __device__ __forceinline__ void fir_pair(const float *win, IDX idx, CFloatPtr ta
 #pragma unroll
           for (int q = 0; q < 8; ++q) tc[i0 + q] = chunk[q];
         }
-        acc0 = fmaf(tc[i0], tv[j], acc0);
+        acc0 = pk_fma(splat(tc[i0]), tv[j], acc0);
       }
-      if (i1 >= 0 && i1 < NT) acc1 = fmaf(tc[i1], tv[j], acc1);
+      if (i1 >= 0 && i1 < NT) acc1 = pk_fma(splat(tc[i1]), tv[j], acc1);
     }
   }
 }
@@ -335,7 +369,6 @@ __device__ __forceinline__ NcoPtr fresh_nco(NcoPtr p) {
   asm volatile("" : "+s"(p));
   return p;
 }
-
 
 // ------------------------------------------------------------------------------------------
 // The fused kernel, FFT_LENGTH = 512
@@ -353,7 +386,9 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
     const float4 *src = reinterpret_cast<const float4 *>(a.tab);
     float4 *dst = reinterpret_cast<float4 *>(smem);
 #pragma unroll
-    for (int i = threadIdx.x; i < kLdsTabFloats / 4; i += 256) dst[i] = src[i];
+    for (int i = threadIdx.x; i < (512 + 448) / 2; i += 256) dst[i] = src[i];  // mask, tw1
+    if (threadIdx.x < 56)  // tw2[q][l1] = table entry [q][lane = l1]
+      reinterpret_cast<float2 *>(smem)[kLdsTabTw2 + threadIdx.x] = a.tab[kTabTw2 + 64 * (threadIdx.x >> 3) + (threadIdx.x & 7)];
   }
   // per-lane constants of the DC high-pass scan
   const float2 hp8 = a.tab[kTabHp8 + lane];
@@ -362,7 +397,7 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
   if (ch >= a.nchan) return;  // whole wave leaves; no further workgroup barriers
 
   const cf *ltab = reinterpret_cast<const cf *>(smem);
-  float *lds = smem + kLdsWaveBase + wv * kLdsFloatsPerWave;
+  float *lds = smem + kLdsTabFloats + wv * kLdsFloatsPerWave;
   float *st = a.state + (size_t)ch * state_floats(N);
   // coefficients are read-only for the kernel: constant address space -> scalar (SMEM) loads,
   // re-derived through an opaque asm per phase so the compiler keeps the tap loads next to
@@ -398,48 +433,53 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
 
     // ---- delay lines HBM -> LDS (every frame is self-contained: load state, run, store state)
     wave_sync();
-    if (lane < 7) {
-      *reinterpret_cast<float4 *>(lds + kXI + 4 * lane) = *reinterpret_cast<const float4 *>(st + kStDec1I + 4 * lane);
-      *reinterpret_cast<float4 *>(lds + kXQ + 4 * lane) = *reinterpret_cast<const float4 *>(st + kStDec1Q + 4 * lane);
-    }
-    if (lane < 12) {
-      *reinterpret_cast<float4 *>(lds + kY1I + 4 * lane) = *reinterpret_cast<const float4 *>(st + kStDec2I + 4 * lane);
-      *reinterpret_cast<float4 *>(lds + kY1Q + 4 * lane) = *reinterpret_cast<const float4 *>(st + kStDec2Q + 4 * lane);
-    }
+    if (lane < 14)
+      *reinterpret_cast<float4 *>(lds + kX + 2 * xpad(2 * lane)) = *reinterpret_cast<const float4 *>(st + kStDec1 + 4 * lane);
+    if (lane < 24)
+      *reinterpret_cast<float4 *>(lds + kY1 + 4 * lane) = *reinterpret_cast<const float4 *>(st + kStDec2 + 4 * lane);
 
     // gains (Process.cpp:117-134, 165-166).  g_band and -IQAmp are folded into one factor on I
     // (exact whenever either is +-1, which is the firmware default; one rounding otherwise)
-    float g_rf, g_i, g_q, iq_phase;
+    float g_rf, iq_phase;
+    f2 g_iq;
+    bool unit_gain;
     {
       const CoefPtr c = fresh_coef(cf0);
       g_rf = c->sc[kScRfGain];
       const float gb = c->sc[kScBandGain];
       const bool iq_on = c->sc[kScIqCorrOn] != 0.0f;
-      g_i = iq_on ? gb * c->sc[kScNegIqAmp] : gb;
-      g_q = gb;
+      g_iq = f2{iq_on ? gb * c->sc[kScNegIqAmp] : gb, gb};
+      unit_gain = (g_iq.x == 1.0f) && (g_iq.y == 1.0f);
       iq_phase = iq_on ? c->sc[kScIqPhase] : 0.0f;
     }
 
     // ---- Q's DC-block start state = state after ALL of this frame's I (one shared biquad
     // instance runs over I then Q, Process.cpp:127-128).  a1^256 ~ 3e-18, so the last 256 I
     // samples decide it.
-    float dc_carry_i = dc_carry;
-    float dc_carry_q;
+    f2 dc2;  // (carry of the I chain, carry of the Q chain)
     {
       const float x[4] = {tailI.x * g_rf, tailI.y * g_rf, tailI.z * g_rf, tailI.w * g_rf};
-      dc_carry_q = dc_highpass_end_state<4>(x, hp4.x, hp4.y);
+      dc2 = f2{dc_carry, dc_highpass_end_state<4>(x, hp4.x, hp4.y)};
     }
 
-    float y2I[2][2], y2Q[2][2];  // /8 outputs of this frame: m = 128*round + 2*lane + e
-    cf v[8];                     // FFT registers; v[0..3] = previous block, prefetched below
+    cf y2[2][2];  // /8 outputs of this frame: m = 128*round + 2*lane + e
+    cf v[8];      // FFT registers; v[0..3] = previous block, prefetched below
 
 #pragma unroll
     for (int rd = 0; rd < 2; ++rd) {
 #pragma unroll 1
       for (int h = 0; h < 2; ++h) {
         const int s = 2 * rd + h;
-        float xi[8] = {nI0.x, nI0.y, nI0.z, nI0.w, nI1.x, nI1.y, nI1.z, nI1.w};
-        float xq[8] = {nQ0.x, nQ0.y, nQ0.z, nQ0.w, nQ1.x, nQ1.y, nQ1.z, nQ1.w};
+        // -- RF gain (Process.cpp:117-119); the multiply also interleaves I and Q into pairs
+        cf z[8];
+        z[0] = cf{nI0.x * g_rf, nQ0.x * g_rf};
+        z[1] = cf{nI0.y * g_rf, nQ0.y * g_rf};
+        z[2] = cf{nI0.z * g_rf, nQ0.z * g_rf};
+        z[3] = cf{nI0.w * g_rf, nQ0.w * g_rf};
+        z[4] = cf{nI1.x * g_rf, nQ1.x * g_rf};
+        z[5] = cf{nI1.y * g_rf, nQ1.y * g_rf};
+        z[6] = cf{nI1.z * g_rf, nQ1.z * g_rf};
+        z[7] = cf{nI1.w * g_rf, nQ1.w * g_rf};
         if (s < 3) {  // prefetch the next sub-block
           const int o = 512 * (s + 1) + 8 * lane;
           nI0 = *reinterpret_cast<const float4 *>(gI + o);
@@ -447,36 +487,23 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
           nQ0 = *reinterpret_cast<const float4 *>(gQ + o);
           nQ1 = *reinterpret_cast<const float4 *>(gQ + o + 4);
         } else {  // last sub-block: prefetch the overlap-save "previous" block instead
-          const float2 *ov = reinterpret_cast<const float2 *>(st + kStOverlap);
+          const cf *ov = reinterpret_cast<const cf *>(st + kStOverlap);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float2 t = ov[64 * j + lane];
-            v[j] = cf{t.x, t.y};
-          }
+          for (int j = 0; j < 4; ++j) v[j] = ov[64 * j + lane];
         }
-        // -- RF gain, DC high-pass, band gain / IQ amplitude
+        // -- DC high-pass (127-128), band gain (133-134) / IQ amplitude (166)
+        dc_highpass<8>(z, dc2, lane, hp8.x, hp8.y);
+        if (!unit_gain) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          xi[k] *= g_rf;
-          xq[k] *= g_rf;
-        }
-        dc_highpass<8>(xi, dc_carry_i, lane, hp8.x, hp8.y);
-        dc_highpass<8>(xq, dc_carry_q, lane, hp8.x, hp8.y);
-        if (g_i != 1.0f) {
-#pragma unroll
-          for (int k = 0; k < 8; ++k) xi[k] *= g_i;
-        }
-        if (g_q != 1.0f) {
-#pragma unroll
-          for (int k = 0; k < 8; ++k) xq[k] *= g_q;
+          for (int k = 0; k < 8; ++k) z[k] *= g_iq;
         }
         // -- IQ phase correction (Utility.cpp:178-187)
         if (iq_phase < 0.0f) {
 #pragma unroll
-          for (int k = 0; k < 8; ++k) xq[k] = fmaf(iq_phase, xi[k], xq[k]);
+          for (int k = 0; k < 8; ++k) z[k].y = fmaf(iq_phase, z[k].x, z[k].y);
         } else if (iq_phase > 0.0f) {
 #pragma unroll
-          for (int k = 0; k < 8; ++k) xi[k] = fmaf(iq_phase, xq[k], xi[k]);
+          for (int k = 0; k < 8; ++k) z[k].x = fmaf(iq_phase, z[k].y, z[k].x);
         }
         // -- oscillator for my 8 samples.  Osc_n = V_n * W has phase phase0 + (n+1) dphi.
         const int n0 = 512 * s + 8 * lane;
@@ -514,26 +541,15 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
           base = cmul(cf{t.x, t.y}, cf{cs, sn});
         }
         // -- Fs/4 shift (x j^n, Freq_Shift.cpp:42-65) and NCO mix (Freq_Shift.cpp:138-139):
-        //    (I' + jQ') = (Iex + jQex) * conj(Osc)
-        float mi[8], mq[8];
+        //    (I' + jQ') = (I + jQ) j^k conj(Osc_k) = (I + jQ) conj(base wk''),  wk'' = wk (-j)^k
+        //    (the host pre-rotates the per-channel constants, so the Fs/4 shift costs nothing)
         const NcoPtr ncw = fresh_nco(nco);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           const cf w = cf{ncw->wk[k][0], ncw->wk[k][1]};
-          cf osc = cmul(base, w);
-          if (transient) {
-            osc.x *= amp[k];
-            osc.y *= amp[k];
-          }
-          float ex_i, ex_q;
-          switch (k & 3) {
-            case 0: ex_i = xi[k]; ex_q = xq[k]; break;
-            case 1: ex_i = -xq[k]; ex_q = xi[k]; break;
-            case 2: ex_i = -xi[k]; ex_q = -xq[k]; break;
-            default: ex_i = xq[k]; ex_q = -xi[k]; break;
-          }
-          mi[k] = fmaf(ex_i, osc.x, ex_q * osc.y);
-          mq[k] = fmaf(ex_q, osc.x, -(ex_i * osc.y));
+          cf osc = cmul_s(base, w);
+          if (transient) osc *= splat(amp[k]);
+          z[k] = cmulc(z[k], osc);
         }
         if (transient) {
           const double rs = uniform_f64(fresh_nco(nco)->r_star_sq);
@@ -543,46 +559,32 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
           float *dn = a.dbg_nco + ((size_t)ch * a.nframes + f) * (2 * L);
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
-            dn[n0 + k] = mi[k];
-            dn[L + n0 + k] = mq[k];
+            dn[n0 + k] = z[k].x;
+            dn[L + n0 + k] = z[k].y;
           }
         }
         // -- stage into LDS, then decimate by 4 (28 taps): outputs m = 2*lane, 2*lane+1
         wave_sync();
-        {
-          const int j0 = xpad(28 + 8 * lane), j1 = xpad(32 + 8 * lane);
-          *reinterpret_cast<float4 *>(lds + kXI + j0) = make_float4(mi[0], mi[1], mi[2], mi[3]);
-          *reinterpret_cast<float4 *>(lds + kXI + j1) = make_float4(mi[4], mi[5], mi[6], mi[7]);
-          *reinterpret_cast<float4 *>(lds + kXQ + j0) = make_float4(mq[0], mq[1], mq[2], mq[3]);
-          *reinterpret_cast<float4 *>(lds + kXQ + j1) = make_float4(mq[4], mq[5], mq[6], mq[7]);
-        }
+        float *xw = lds + kX + 20 * lane;  // lane stride: 8 complex + 1 pad slot = 20 floats
+#pragma unroll
+        for (int i = 0; i < 4; ++i)  // logical 28 + 8 lane + 2 i  ->  xpad() - 10 lane is a constant
+          *reinterpret_cast<float4 *>(xw + 2 * (xpad(28 + 2 * i))) =
+              make_float4(z[2 * i].x, z[2 * i].y, z[2 * i + 1].x, z[2 * i + 1].y);
         wave_sync();
-        float o1[2][2];  // [I/Q][e]
+        cf o1[2];
         // arm_fir_decimate_f32: y[m] = sum_i c[i] * state[4m + i]; state[i] = buf[i + 1]
         {
-          const int wbase = xpad(8 * lane);
-          // a lane's 36-float window [8 lane, 8 lane + 36) can cross one 128-float pad
-          // boundary: use the exact padded index per float4
-          auto pidx = [&](int o) { return xpad(8 * lane + o) - wbase; };
-          fir_pair<kDec1Taps, 1, 5, 9, 5>(lds + kXI + wbase, pidx, (CFloatPtr)cf0->dec1, o1[0][0], o1[0][1]);
-          wave_sync();
-          fir_pair<kDec1Taps, 1, 5, 9, 5>(lds + kXQ + wbase, pidx, (CFloatPtr)cf0->dec1, o1[1][0], o1[1][1]);
+          auto pidx = [](int o) { return xpad(o); };  // window-relative, identical for every lane
+          fir_pair<kDec1Taps, 1, 5, 18, 6>(xw, pidx, (CFloatPtr)cf0->dec1, o1[0], o1[1]);
         }
         // -- roll the /4 history (logical 512..539 -> 0..27) and append the /4 outputs
         {
-          float4 hI = make_float4(0, 0, 0, 0), hQ = make_float4(0, 0, 0, 0);
-          if (lane < 7) {
-            hI = lds4(lds + kXI + xpad(512 + 4 * lane));
-            hQ = lds4(lds + kXQ + xpad(512 + 4 * lane));
-          }
+          float4 hh = make_float4(0, 0, 0, 0);
+          if (lane < 14) hh = lds4(lds + kX + 2 * xpad(512 + 2 * lane));
           wave_sync();
-          if (lane < 7) {
-            *reinterpret_cast<float4 *>(lds + kXI + 4 * lane) = hI;
-            *reinterpret_cast<float4 *>(lds + kXQ + 4 * lane) = hQ;
-          }
-          const int j = 48 + 128 * h + 2 * lane;
-          *reinterpret_cast<float2 *>(lds + kY1I + j) = make_float2(o1[0][0], o1[0][1]);
-          *reinterpret_cast<float2 *>(lds + kY1Q + j) = make_float2(o1[1][0], o1[1][1]);
+          if (lane < 14) *reinterpret_cast<float4 *>(lds + kX + 2 * xpad(2 * lane)) = hh;
+          *reinterpret_cast<float4 *>(lds + kY1 + 2 * (48 + 128 * h + 2 * lane)) =
+              make_float4(o1[0].x, o1[0].y, o1[1].x, o1[1].y);
         }
       }  // h
       // ---- decimate by 2 (46 taps) over the 256 new /4 samples: m = 2*lane, 2*lane+1
@@ -590,37 +592,23 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
       // y[m] = sum_i c[i] * state[2m + i]; state[i] = buf[i + 3]
       {
         auto lin = [](int o) { return o; };
-        fir_pair<kDec2Taps, 3, 5, 13, 5>(lds + kY1I + 4 * lane, lin, (CFloatPtr)cf0->dec2, y2I[rd][0], y2I[rd][1]);
-        wave_sync();
-        fir_pair<kDec2Taps, 3, 5, 13, 5>(lds + kY1Q + 4 * lane, lin, (CFloatPtr)cf0->dec2, y2Q[rd][0], y2Q[rd][1]);
+        fir_pair<kDec2Taps, 3, 5, 26, 6>(lds + kY1 + 8 * lane, lin, (CFloatPtr)cf0->dec2, y2[rd][0], y2[rd][1]);
       }
       {  // roll the /2 history: logical 256..303 -> 0..47
-        float4 hI = make_float4(0, 0, 0, 0), hQ = make_float4(0, 0, 0, 0);
-        if (lane < 12) {
-          hI = lds4(lds + kY1I + 256 + 4 * lane);
-          hQ = lds4(lds + kY1Q + 256 + 4 * lane);
-        }
+        float4 hh = make_float4(0, 0, 0, 0);
+        if (lane < 24) hh = lds4(lds + kY1 + 2 * (256 + 2 * lane));
         wave_sync();
-        if (lane < 12) {
-          *reinterpret_cast<float4 *>(lds + kY1I + 4 * lane) = hI;
-          *reinterpret_cast<float4 *>(lds + kY1Q + 4 * lane) = hQ;
-        }
+        if (lane < 24) *reinterpret_cast<float4 *>(lds + kY1 + 4 * lane) = hh;
       }
     }  // rd
     phase0 += (uint64_t)L * dphi;
-    dc_carry = dc_carry_q;  // the shared biquad ends the frame on Q
+    dc_carry = uniform_f32(dc2.y);  // the shared biquad ends the frame on Q
 
     // ---- delay lines back to HBM (the LDS copies are about to be reused as scratch); issue
     // the small back-end history loads now so the FFT hides their latency
     wave_sync();
-    if (lane < 7) {
-      *reinterpret_cast<float4 *>(st + kStDec1I + 4 * lane) = lds4(lds + kXI + 4 * lane);
-      *reinterpret_cast<float4 *>(st + kStDec1Q + 4 * lane) = lds4(lds + kXQ + 4 * lane);
-    }
-    if (lane < 12) {
-      *reinterpret_cast<float4 *>(st + kStDec2I + 4 * lane) = lds4(lds + kY1I + 4 * lane);
-      *reinterpret_cast<float4 *>(st + kStDec2Q + 4 * lane) = lds4(lds + kY1Q + 4 * lane);
-    }
+    if (lane < 14) *reinterpret_cast<float4 *>(st + kStDec1 + 4 * lane) = lds4(lds + kX + 2 * xpad(2 * lane));
+    if (lane < 24) *reinterpret_cast<float4 *>(st + kStDec2 + 4 * lane) = lds4(lds + kY1 + 4 * lane);
     float4 hist1 = make_float4(0, 0, 0, 0);
     if (lane < 6) hist1 = *reinterpret_cast<const float4 *>(st + kStInt1 + 4 * lane);
     float hist2 = 0.0f;
@@ -632,18 +620,15 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
 #pragma unroll
     for (int rd = 0; rd < 2; ++rd)
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        y2I[rd][e] *= level;
-        y2Q[rd][e] *= level;
-      }
+      for (int e = 0; e < 2; ++e) y2[rd][e] *= splat(level);
     if (DEBUG && a.dbg_dec) {
       float *dd = a.dbg_dec + ((size_t)ch * a.nframes + f) * N;
 #pragma unroll
       for (int rd = 0; rd < 2; ++rd)
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-          dd[128 * rd + 2 * lane + e] = y2I[rd][e];
-          dd[D + 128 * rd + 2 * lane + e] = y2Q[rd][e];
+          dd[128 * rd + 2 * lane + e] = y2[rd][e].x;
+          dd[D + 128 * rd + 2 * lane + e] = y2[rd][e].y;
         }
     }
 
@@ -653,13 +638,13 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
 #pragma unroll
       for (int rd = 0; rd < 2; ++rd)
         *reinterpret_cast<float4 *>(lds + 2 * (128 * rd + 2 * lane)) =
-            make_float4(y2I[rd][0], y2Q[rd][0], y2I[rd][1], y2Q[rd][1]);
+            make_float4(y2[rd][0].x, y2[rd][0].y, y2[rd][1].x, y2[rd][1].y);
       wave_sync();
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[4 + j] = tb[lane + 64 * j];
-      float2 *ov = reinterpret_cast<float2 *>(st + kStOverlap);
+      cf *ov = reinterpret_cast<cf *>(st + kStOverlap);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) ov[64 * j + lane] = make_float2(v[4 + j].x, v[4 + j].y);
+      for (int j = 0; j < 4; ++j) ov[64 * j + lane] = v[4 + j];
     }
 
     // ---- FFT, x mask, inverse FFT (Process.cpp:535-595).  The mask table is pre-scaled by 1/N.
@@ -667,12 +652,12 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
       cf tw1[7], tw2[7];
 #pragma unroll
       for (int q = 0; q < 7; ++q) {
-        tw1[q] = ltab[kTabTw1 + 64 * q + lane];
-        tw2[q] = ltab[kTabTw2 + 64 * q + lane];
+        tw1[q] = ltab[kLdsTabTw1 + 64 * q + lane];
+        tw2[q] = ltab[kLdsTabTw2 + 8 * q + (lane & 7)];
       }
       fft512<false>(v, tw1, tw2, lds, lane);
 #pragma unroll
-      for (int r = 0; r < 8; ++r) v[r] = cmul(v[r], ltab[kTabMask + 64 * r + lane]);
+      for (int r = 0; r < 8; ++r) v[r] = cmul(v[r], ltab[kLdsTabMask + 64 * r + lane]);
       fft512<true>(v, tw1, tw2, lds, lane);
     }
 
@@ -696,7 +681,7 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
       for (int j = 0; j < 4; ++j) lds[24 + lane + 64 * j] = aud[j];
     }
     wave_sync();
-    float u1[8];
+    f2 u1[4];  // outputs (2n, 2n+1) of input n = 4 lane + u
     {
       float w[28];
 #pragma unroll
@@ -708,9 +693,10 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
         w[4 * i + 3] = t.w;
       }
       if (lane < 6) *reinterpret_cast<float4 *>(st + kStInt1 + 4 * lane) = lds4(lds + 256 + 4 * lane);
-      // arm_fir_interpolate_f32: out[2n + j - 1] = sum_t state[n + t] * c[(2 - j) + 2 t]
+      // arm_fir_interpolate_f32: out[2n + j - 1] = sum_t state[n + t] * c[(2 - j) + 2 t]:
+      // (out[2n], out[2n+1]) += state[n+t] * (c[2t+1], c[2t])  -- one packed FMA per tap
 #pragma unroll
-      for (int i = 0; i < 8; ++i) u1[i] = 0.0f;
+      for (int u = 0; u < 4; ++u) u1[u] = splat(0.0f);
 #pragma unroll
       for (int b = 0; b < 24; b += 8) {
         float ci[16];
@@ -718,11 +704,7 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
 #pragma unroll
-          for (int t = 0; t < 8; ++t) {
-            const float x = w[u + b + t + 1];
-            u1[2 * u] = fmaf(x, ci[1 + 2 * t], u1[2 * u]);
-            u1[2 * u + 1] = fmaf(x, ci[2 * t], u1[2 * u + 1]);
-          }
+          for (int t = 0; t < 8; ++t) u1[u] = pk_fma(splat(w[u + b + t + 1]), f2{ci[1 + 2 * t], ci[2 * t]}, u1[u]);
         }
       }
     }
@@ -733,31 +715,34 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
       const float out_scale = fresh_coef(cf0)->sc[kScOutScale];
       float c4[32];
       load_taps<32>(c4, (CFloatPtr)cf0->int2);
+      const float x1[8] = {u1[0].x, u1[0].y, u1[1].x, u1[1].y, u1[2].x, u1[2].y, u1[3].x, u1[3].y};
 #pragma unroll
       for (int i = 0; i < 7; ++i) {
-        const float up = lane_up1(u1[i + 1]);
-        const float h = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hist2), i + 1));
-        w[i] = (lane == 0) ? h : up;
+        const float up = lane_up1(x1[i + 1]);
+        const float hs = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hist2), i + 1));
+        w[i] = (lane == 0) ? hs : up;
       }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) w[7 + i] = u1[i];
+      for (int i = 0; i < 8; ++i) w[7 + i] = x1[i];
       if (lane == 63) {
-        *reinterpret_cast<float4 *>(st + kStInt2) = make_float4(0.0f, u1[1], u1[2], u1[3]);
-        *reinterpret_cast<float4 *>(st + kStInt2 + 4) = make_float4(u1[4], u1[5], u1[6], u1[7]);
+        *reinterpret_cast<float4 *>(st + kStInt2) = make_float4(0.0f, x1[1], x1[2], x1[3]);
+        *reinterpret_cast<float4 *>(st + kStInt2 + 4) = make_float4(x1[4], x1[5], x1[6], x1[7]);
       }
-      // out[4n + j - 1] = sum_t state[n + t] * c[(4 - j) + 4 t],  state[n + t] = w[u + t]
+      // out[4n + j - 1] = sum_t state[n + t] * c[(4 - j) + 4 t],  state[n + t] = w[u + t]:
+      // (out[4n], out[4n+1]) += w * (c[4t+3], c[4t+2]);  (out[4n+2], out[4n+3]) += w * (c[4t+1], c[4t])
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        float o[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        f2 o01 = splat(0.0f), o23 = splat(0.0f);
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-          const float x = w[u + t];
-#pragma unroll
-          for (int j = 1; j <= 4; ++j) o[j - 1] = fmaf(x, c4[(4 - j) + 4 * t], o[j - 1]);
+          const f2 x = splat(w[u + t]);
+          o01 = pk_fma(x, f2{c4[4 * t + 3], c4[4 * t + 2]}, o01);
+          o23 = pk_fma(x, f2{c4[4 * t + 1], c4[4 * t]}, o23);
         }
         // ---- volume (Process.cpp:929) and store
-        *reinterpret_cast<float4 *>(gO + 32 * lane + 4 * u) =
-            make_float4(o[0] * out_scale, o[1] * out_scale, o[2] * out_scale, o[3] * out_scale);
+        o01 *= splat(out_scale);
+        o23 *= splat(out_scale);
+        *reinterpret_cast<float4 *>(gO + 32 * lane + 4 * u) = make_float4(o01.x, o01.y, o23.x, o23.y);
       }
     }
   }  // frames

@@ -177,7 +177,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
 
-    if not torch.isfinite(outs[(args.warmup + args.steps - 1) % RING]).all():
+    if not os.environ.get("T41RX_BENCH_NOCHECK") and not torch.isfinite(outs[(args.warmup + args.steps - 1) % RING]).all():
         raise SystemExit("non-finite audio output")
 
     samples_per_step = N_CHANNELS * FRAME_LEN

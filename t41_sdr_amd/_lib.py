@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libt41rx.so")
+LIB_PATH = os.environ.get("T41RX_LIB", os.path.join(_HERE, "libt41rx.so"))  # override: kernel experiments
 
 T41RX_OK = 0
 ERR_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_NOMEM, ERR_STATE = -1, -2, -3, -4, -5

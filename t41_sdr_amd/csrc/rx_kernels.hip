@@ -53,6 +53,15 @@ __device__ __forceinline__ void wave_sync() {
   asm volatile("" ::: "memory");
 }
 
+// Timing experiments (tools/build_ablations.sh): T41RX_ABLATE = n cuts stages from the END of the
+// chain (1 interpolators, 2 FFTs, 3 /2 decimator, 4 /4 decimator, 5 NCO, 6 DC high-pass, 7/8 ideal
+// store/load patterns); 9 keeps all arithmetic but makes every wave use the same 16 channels'
+// buffers (cache-resident I/O).  Outputs are WRONG for n > 0; the product builds with 0.
+#ifndef T41RX_ABLATE
+#define T41RX_ABLATE 0
+#endif
+#define T41RX_CUT(n) (T41RX_ABLATE >= (n) && T41RX_ABLATE <= 8)
+
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef f2 cf;  // .x = re / I, .y = im / Q, one even-aligned VGPR pair
 
@@ -398,7 +407,7 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
 
   const cf *ltab = reinterpret_cast<const cf *>(smem);
   float *lds = smem + kLdsTabFloats + wv * kLdsFloatsPerWave;
-  float *st = a.state + (size_t)ch * state_floats(N);
+  float *st = a.state + (size_t)(T41RX_ABLATE == 9 ? (ch & 15) : ch) * state_floats(N);
   // coefficients are read-only for the kernel: constant address space -> scalar (SMEM) loads,
   // re-derived through an opaque asm per phase so the compiler keeps the tap loads next to
   // their use instead of hoisting all 180 of them (and spilling SGPRs).
@@ -419,7 +428,7 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
   }
 
   for (int f = 0; f < a.nframes; ++f) {
-    const size_t fbase = ((size_t)ch * a.nframes + f) * L;
+    const size_t fbase = ((size_t)(T41RX_ABLATE == 9 ? (ch & 15) : ch) * a.nframes + f) * L;
     const float *__restrict__ gI = a.I + fbase;
     const float *__restrict__ gQ = a.Q + fbase;
     float *__restrict__ gO = a.out + fbase;
@@ -481,18 +490,19 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
         z[6] = cf{nI1.z * g_rf, nQ1.z * g_rf};
         z[7] = cf{nI1.w * g_rf, nQ1.w * g_rf};
         if (s < 3) {  // prefetch the next sub-block
-          const int o = 512 * (s + 1) + 8 * lane;
+          const int o = 512 * (s + 1) + (T41RX_CUT(8) ? 4 : 8) * lane;
+          const int o2 = T41RX_CUT(8) ? 256 : 4;
           nI0 = *reinterpret_cast<const float4 *>(gI + o);
-          nI1 = *reinterpret_cast<const float4 *>(gI + o + 4);
+          nI1 = *reinterpret_cast<const float4 *>(gI + o + o2);
           nQ0 = *reinterpret_cast<const float4 *>(gQ + o);
-          nQ1 = *reinterpret_cast<const float4 *>(gQ + o + 4);
+          nQ1 = *reinterpret_cast<const float4 *>(gQ + o + o2);
         } else {  // last sub-block: prefetch the overlap-save "previous" block instead
           const cf *ov = reinterpret_cast<const cf *>(st + kStOverlap);
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = ov[64 * j + lane];
         }
         // -- DC high-pass (127-128), band gain (133-134) / IQ amplitude (166)
-        dc_highpass<8>(z, dc2, lane, hp8.x, hp8.y);
+        if (!T41RX_CUT(6)) dc_highpass<8>(z, dc2, lane, hp8.x, hp8.y);
         if (!unit_gain) {
 #pragma unroll
           for (int k = 0; k < 8; ++k) z[k] *= g_iq;
@@ -547,6 +557,7 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           const cf w = cf{ncw->wk[k][0], ncw->wk[k][1]};
+          if (T41RX_CUT(5)) continue;
           cf osc = cmul_s(base, w);
           if (transient) osc *= splat(amp[k]);
           z[k] = cmulc(z[k], osc);
@@ -575,7 +586,12 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
         // arm_fir_decimate_f32: y[m] = sum_i c[i] * state[4m + i]; state[i] = buf[i + 1]
         {
           auto pidx = [](int o) { return xpad(o); };  // window-relative, identical for every lane
-          fir_pair<kDec1Taps, 1, 5, 18, 6>(xw, pidx, (CFloatPtr)cf0->dec1, o1[0], o1[1]);
+          if (!T41RX_CUT(4)) {
+            fir_pair<kDec1Taps, 1, 5, 18, 6>(xw, pidx, (CFloatPtr)cf0->dec1, o1[0], o1[1]);
+          } else {
+            o1[0] = *reinterpret_cast<cf *>(xw);
+            o1[1] = *reinterpret_cast<cf *>(xw + 8);
+          }
         }
         // -- roll the /4 history (logical 512..539 -> 0..27) and append the /4 outputs
         {
@@ -592,7 +608,12 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
       // y[m] = sum_i c[i] * state[2m + i]; state[i] = buf[i + 3]
       {
         auto lin = [](int o) { return o; };
-        fir_pair<kDec2Taps, 3, 5, 26, 6>(lds + kY1 + 8 * lane, lin, (CFloatPtr)cf0->dec2, y2[rd][0], y2[rd][1]);
+        if (!T41RX_CUT(3)) {
+          fir_pair<kDec2Taps, 3, 5, 26, 6>(lds + kY1 + 8 * lane, lin, (CFloatPtr)cf0->dec2, y2[rd][0], y2[rd][1]);
+        } else {
+          y2[rd][0] = *reinterpret_cast<cf *>(lds + kY1 + 8 * lane);
+          y2[rd][1] = *reinterpret_cast<cf *>(lds + kY1 + 8 * lane + 2);
+        }
       }
       {  // roll the /2 history: logical 256..303 -> 0..47
         float4 hh = make_float4(0, 0, 0, 0);
@@ -655,10 +676,12 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
         tw1[q] = ltab[kLdsTabTw1 + 64 * q + lane];
         tw2[q] = ltab[kLdsTabTw2 + 8 * q + (lane & 7)];
       }
-      fft512<false>(v, tw1, tw2, lds, lane);
+      if (!T41RX_CUT(2)) {
+        fft512<false>(v, tw1, tw2, lds, lane);
 #pragma unroll
-      for (int r = 0; r < 8; ++r) v[r] = cmul(v[r], ltab[kLdsTabMask + 64 * r + lane]);
-      fft512<true>(v, tw1, tw2, lds, lane);
+        for (int r = 0; r < 8; ++r) v[r] = cmul(v[r], ltab[kLdsTabMask + 64 * r + lane]);
+        fft512<true>(v, tw1, tw2, lds, lane);
+      }
     }
 
     // ---- AGC off: fixed gain on the valid half (DSP_Fn.cpp:494-502); SSB: audio = Re
@@ -672,6 +695,12 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
       for (int j = 0; j < 4; ++j) dm[lane + 64 * j] = aud[j];
     }
 
+    if (T41RX_CUT(1)) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        *reinterpret_cast<float4 *>(gO + (T41RX_CUT(7) ? 4 * lane + 256 * u : 32 * lane + 4 * u)) = make_float4(aud[0], aud[1], aud[2], aud[3]);
+      continue;
+    }
     // ---- interpolate by 2 (48 taps, phase length 24): inputs n = 4 lane .. 4 lane + 3
     // LDS buf: [0] pad, [1..23] history, [24 + i] new sample i
     wave_sync();

@@ -207,6 +207,13 @@ template <int CTRL, int ROW_MASK, bool BOUND>
 __device__ __forceinline__ f2 dpp_f2(f2 src) {
   return f2{dpp_f<CTRL, ROW_MASK, BOUND>(0.0f, src.x), dpp_f<CTRL, ROW_MASK, BOUND>(0.0f, src.y)};
 }
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ __forceinline__ double dpp_d(double x) {
+  const long long u = __double_as_longlong(x);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)u, CTRL, ROW_MASK, 0xf, BOUND);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(u >> 32), CTRL, ROW_MASK, 0xf, BOUND);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 // value of lane-1 (lane 0 gets 0)
 __device__ __forceinline__ float lane_up1(float v) { return dpp_f<kDppWaveShr1, 0xf, true>(0.0f, v); }
 
@@ -378,6 +385,8 @@ __device__ __forceinline__ NcoPtr fresh_nco(NcoPtr p) {
   asm volatile("" : "+s"(p));
   return p;
 }
+
+constexpr int kModeSsb = 0, kModeAm = 1, kModeNfm = 2;  // kernel template MODE
 
 // ------------------------------------------------------------------------------------------
 // The fused kernel, FFT_LENGTH = 512
@@ -653,6 +662,52 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
         }
     }
 
+    // ---- NFM (Process.cpp:716-727): quadri-correlator discriminator on the 256 new complex
+    // samples, hard limiter, then the demodulated REAL audio goes through the same overlap-save
+    // filter with zero imaginary part (Process.cpp:765-816)
+    if (MODE == kModeNfm) {
+      // fmdemod_quadri_K (Demod.h:7) is a double: K * (float expr) / (float expr) in double
+      constexpr double K = 0.340447550238101026565118445432744920253753662109375;
+      const cf *ms = reinterpret_cast<const cf *>(st + kStMisc + kMiscNfmI);
+      const cf last = ms[0];  // nfmdemod()'s "last sample", see the quirk note below
+      float au[2][2];
+#pragma unroll
+      for (int rd = 0; rd < 2; ++rd) {
+        // previous complex sample of m = 128 rd + 2 lane: lane-1's odd sample; lane 0 wraps to the
+        // previous round's last sample
+        cf prev0 = cf{lane_up1(y2[rd][1].x), lane_up1(y2[rd][1].y)};
+        if (rd == 1 && lane == 0)
+          prev0 = cf{__int_as_float(__builtin_amdgcn_readlane(__float_as_int(y2[0][1].x), 63)),
+                     __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y2[0][1].y), 63))};
+        const cf cur0 = y2[rd][0], cur1 = y2[rd][1];
+        // Demod.cpp:229-231: (qnow * ilast - inow * qlast) / (inow^2 + qnow^2)
+        float num0 = cur0.y * prev0.x - cur0.x * prev0.y;
+        const float den0 = cur0.x * cur0.x + cur0.y * cur0.y;
+        const float num1 = cur1.y * cur0.x - cur1.x * cur0.y;
+        const float den1 = cur1.x * cur1.x + cur1.y * cur1.y;
+        if (rd == 0 && lane == 0)  // Demod.cpp:224: first sample of the frame uses the difference form
+          num0 = cur0.x * (cur0.y - last.y) - cur0.y * (cur0.x - last.x);
+        float a0 = (float)(K * (double)num0 / (double)den0);
+        float a1 = (float)(K * (double)num1 / (double)den1);
+        // Process.cpp:719-727: limiter, skips sample 0 of the frame
+        if (!(rd == 0 && lane == 0)) {
+          a0 = (1.0f < a0) ? 1.0f : a0;
+          a0 = (-1.0f > a0) ? -1.0f : a0;
+        }
+        a1 = (1.0f < a1) ? 1.0f : a1;
+        a1 = (-1.0f > a1) ? -1.0f : a1;
+        au[rd][0] = a0;
+        au[rd][1] = a1;
+      }
+      // Demod.cpp:232-233 keeps floats [input_size-2], [input_size-1] of the interleaved buffer
+      // as "last sample": that is complex sample 127 (m = 127: round 0, lane 63, odd), not 255
+      if (lane == 63) *reinterpret_cast<cf *>(st + kStMisc + kMiscNfmI) = y2[0][1];
+#pragma unroll
+      for (int rd = 0; rd < 2; ++rd)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) y2[rd][e] = cf{au[rd][e], 0.0f};
+    }
+
     // ---- overlap-save assemble (Process.cpp:498-522): v[0..3] = previous block, v[4..7] = new
     {
       cf *tb = reinterpret_cast<cf *>(lds);
@@ -684,15 +739,136 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
       }
     }
 
-    // ---- AGC off: fixed gain on the valid half (DSP_Fn.cpp:494-502); SSB: audio = Re
+    // ---- AGC off: fixed gain on the valid half (DSP_Fn.cpp:494-502); SSB/NFM: audio = Re
     float aud[4];
     const float fixed_gain = fresh_coef(cf0)->sc[kScFixedGain];
+    if (MODE != kModeAm) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) aud[j] = fixed_gain * v[4 + j].x;
+      for (int j = 0; j < 4; ++j) aud[j] = fixed_gain * v[4 + j].x;
+    } else {
+      // ---- AM (Process.cpp:697-707): AlphaBetaMag envelope (Utility.cpp:269-285), DC removal
+      // w = m + 0.99 w_old, y = w - w_old, then biquad_lowpass1 (DF1).  Both recurrences run as
+      // wave scans over lane-contiguous chunks of 4 samples.
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const cf g = v[4 + j] * splat(fixed_gain);
+        const float ai = fabsf(g.x), aq = fabsf(g.y);
+        const float hi = fmaxf(ai, aq), lo = fminf(ai, aq);
+        aud[j] = 0.960433870103f * hi + 0.397824734759f * lo;
+      }
+      wave_sync();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) lds[24 + lane + 64 * j] = aud[j];
+      wave_sync();
+      const float4 m4 = lds4(lds + 24 + 4 * lane);
+      const float m[4] = {m4.x, m4.y, m4.z, m4.w};
+      float *ms = st + kStMisc;
+      // -- DC block.  The reference accumulates w ~ 100x the signal in f32; here the scan runs in
+      // f64 (no accumulation noise of its own), state kept as the reference's float wold
+      const double ca = (double)0.99f;
+      double wl[4];
+      {
+        double wprev = (lane == 0) ? (double)ms[kMiscWold] : 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          wprev = (double)m[k] + ca * wprev;
+          wl[k] = wprev;
+        }
+      }
+      double B = wl[3];
+      {
+        const double a4 = ca * ca * ca * ca, a8 = a4 * a4, a16 = a8 * a8, a32 = a16 * a16;
+        double p15 = a4, p31 = a4;  // ca^(4 ((lane&15)+1)), ca^(4 ((lane&31)+1))
+        for (int i = 0; i < (lane & 15); ++i) p15 *= a4;
+        for (int i = 0; i < (lane & 31); ++i) p31 *= a4;
+        B = fma(a4, dpp_d<kDppRowShr1, 0xf, true>(B), B);
+        B = fma(a8, dpp_d<kDppRowShr2, 0xf, true>(B), B);
+        B = fma(a16, dpp_d<kDppRowShr4, 0xf, true>(B), B);
+        B = fma(a32, dpp_d<kDppRowShr8, 0xf, true>(B), B);
+        B = fma(p15, dpp_d<kDppRowBcast15, 0xa, false>(B), B);
+        B = fma(p31, dpp_d<kDppRowBcast31, 0xc, false>(B), B);
+        const double e = dpp_d<kDppWaveShr1, 0xf, true>(B);  // w just before my first sample (lane 0: already included)
+        double wk_prev = (lane == 0) ? (double)ms[kMiscWold] : e;
+        double apow = ca;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const double wt = (lane == 0) ? wl[k] : wl[k] + apow * e;
+          aud[k] = (float)(wt - wk_prev);
+          wk_prev = wt;
+          apow *= ca;
+        }
+        if (lane == 63) ms[kMiscWold] = (float)wk_prev;
+      }
+      // -- biquad_lowpass1, DF1: y = b0 x + b1 x1 + b2 x2 + a1 y1 + a2 y2 (a's pre-negated)
+      {
+        const CoefPtr c = fresh_coef(cf0);
+        const float b0 = c->lp1[0], b1 = c->lp1[1], b2 = c->lp1[2], a1 = c->lp1[3], a2 = c->lp1[4];
+        const float4 sv = *reinterpret_cast<const float4 *>(ms + kMiscLp1);  // x1, x2, y1, y2
+        float xm1 = lane_up1(aud[3]), xm2 = lane_up1(aud[2]);
+        if (lane == 0) {
+          xm1 = sv.x;
+          xm2 = sv.y;
+        }
+        float y[4];
+        float s1 = (lane == 0) ? sv.z : 0.0f, s2 = (lane == 0) ? sv.w : 0.0f;  // y[n-1], y[n-2]
+        {
+          float x1 = xm1, x2 = xm2;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float u = b0 * aud[k] + b1 * x1 + b2 * x2;
+            const float yy = u + a1 * s1 + a2 * s2;
+            x2 = x1;
+            x1 = aud[k];
+            s2 = s1;
+            s1 = yy;
+            y[k] = yy;
+          }
+        }
+        // state transition over one lane (4 samples): s_out = P s_in + (s1, s2), P = M^4,
+        // M = [[a1, a2], [1, 0]]; scan with 2x2 matrix powers
+        struct M2 { float a, b, c, d; };
+        auto mm = [](M2 x, M2 y) { return M2{x.a * y.a + x.b * y.c, x.a * y.b + x.b * y.d, x.c * y.a + x.d * y.c, x.c * y.b + x.d * y.d}; };
+        const M2 M{a1, a2, 1.0f, 0.0f};
+        const M2 Mq = mm(M, M);
+        const M2 P1 = mm(Mq, Mq), P2 = mm(P1, P1), P4 = mm(P2, P2), P8 = mm(P4, P4);
+        M2 Q15 = P1, Q31 = P1;
+        for (int i = 0; i < (lane & 15); ++i) Q15 = mm(Q15, P1);
+        for (int i = 0; i < (lane & 31); ++i) Q31 = mm(Q31, P1);
+        auto step = [&](M2 P, float o1, float o2) {
+          s1 = s1 + P.a * o1 + P.b * o2;
+          s2 = s2 + P.c * o1 + P.d * o2;
+        };
+        {
+          float o1 = dpp_f<kDppRowShr1, 0xf, true>(0.0f, s1), o2 = dpp_f<kDppRowShr1, 0xf, true>(0.0f, s2);
+          step(P1, o1, o2);
+          o1 = dpp_f<kDppRowShr2, 0xf, true>(0.0f, s1), o2 = dpp_f<kDppRowShr2, 0xf, true>(0.0f, s2);
+          step(P2, o1, o2);
+          o1 = dpp_f<kDppRowShr4, 0xf, true>(0.0f, s1), o2 = dpp_f<kDppRowShr4, 0xf, true>(0.0f, s2);
+          step(P4, o1, o2);
+          o1 = dpp_f<kDppRowShr8, 0xf, true>(0.0f, s1), o2 = dpp_f<kDppRowShr8, 0xf, true>(0.0f, s2);
+          step(P8, o1, o2);
+          o1 = dpp_f<kDppRowBcast15, 0xa, false>(0.0f, s1), o2 = dpp_f<kDppRowBcast15, 0xa, false>(0.0f, s2);
+          step(Q15, o1, o2);
+          o1 = dpp_f<kDppRowBcast31, 0xc, false>(0.0f, s1), o2 = dpp_f<kDppRowBcast31, 0xc, false>(0.0f, s2);
+          step(Q31, o1, o2);
+        }
+        // carry entering my chunk = inclusive state of lane-1; fix up y_k += (M^(k+1) e)[0]
+        const float e1 = lane_up1(s1), e2 = lane_up1(s2);
+        M2 Mk = M;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          y[k] += Mk.a * e1 + Mk.b * e2;
+          Mk = mm(M, Mk);
+        }
+        if (lane == 63) *reinterpret_cast<float4 *>(ms + kMiscLp1) = make_float4(aud[3], aud[2], y[3], y[2]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) aud[k] = y[k];
+      }
+    }
     if (DEBUG && a.dbg_demod) {
       float *dm = a.dbg_demod + ((size_t)ch * a.nframes + f) * D;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) dm[lane + 64 * j] = aud[j];
+      for (int j = 0; j < 4; ++j) dm[(MODE == kModeAm) ? 4 * lane + j : lane + 64 * j] = aud[j];
     }
 
     if (T41RX_CUT(1)) {
@@ -706,8 +882,12 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
     wave_sync();
     {
       if (lane < 6) *reinterpret_cast<float4 *>(lds + 4 * lane) = hist1;
+      if (MODE == kModeAm) {
+        *reinterpret_cast<float4 *>(lds + 24 + 4 * lane) = make_float4(aud[0], aud[1], aud[2], aud[3]);
+      } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) lds[24 + lane + 64 * j] = aud[j];
+        for (int j = 0; j < 4; ++j) lds[24 + lane + 64 * j] = aud[j];
+      }
     }
     wave_sync();
     f2 u1[4];  // outputs (2n, 2n+1) of input n = 4 lane + u
@@ -806,7 +986,11 @@ hipError_t launch_rx(const RxArgs &a, int fft_length, int mode, hipStream_t s) {
   switch (mode) {
     case T41RX_DEMOD_USB:
     case T41RX_DEMOD_LSB:
-      return launch512<0>(a, s, debug);
+      return launch512<kModeSsb>(a, s, debug);
+    case T41RX_DEMOD_AM:
+      return launch512<kModeAm>(a, s, debug);
+    case T41RX_DEMOD_NFM:
+      return launch512<kModeNfm>(a, s, debug);
     default:
       return hipErrorInvalidValue;
   }

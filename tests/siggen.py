@@ -53,3 +53,19 @@ def block_rel_err(a, b, frame_len):
     den = np.abs(b).max(axis=2)
     num = np.abs(a - b).max(axis=2)
     return np.where(den < 1e-6, num, num / np.maximum(den, 1e-30))
+
+
+def make_fm(n_channels, n_samples, nco_hz, seed=0x464D, noise=0.003):
+    """narrow-band FM carriers (one per channel) that land at 0 Hz after +Fs/4 and -NCO
+    (NFM path: no I sign flip), sinusoidal modulation 300..2500 Hz, index 0.5..2.5"""
+    nco_hz = np.broadcast_to(np.asarray(nco_hz, dtype=np.float64), (n_channels,))
+    I = np.empty((n_channels, n_samples), dtype=np.float32)
+    Q = np.empty((n_channels, n_samples), dtype=np.float32)
+    n = np.arange(n_samples, dtype=np.float64)
+    for c in range(n_channels):
+        rng = np.random.default_rng(seed + c)
+        fm, dev, amp = rng.uniform(300, 2500), rng.uniform(0.5, 2.5), rng.uniform(0.1, 0.5)
+        ph = 2 * np.pi * (-48000.0 + nco_hz[c]) / FS * n + dev * np.sin(2 * np.pi * fm / FS * n + rng.uniform(0, 6.28))
+        x = amp * np.exp(1j * ph) + noise * (rng.standard_normal(n_samples) + 1j * rng.standard_normal(n_samples))
+        I[c], Q[c] = x.real, x.imag
+    return I, Q

@@ -19,6 +19,7 @@ pytestmark = pytest.mark.gpu
 
 L = 2048
 TOL = 1e-5
+AM_TOL = 5e-5  # see the note above test_parity_am
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
@@ -74,14 +75,50 @@ def test_parity_vs_oracle(T, kw):
     assert err.max() <= TOL, "worst block-relative error %.3e at %s" % (err.max(), np.unravel_index(err.argmax(), err.shape))
 
 
-@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "usb*.npz")) +
-                                        glob.glob(os.path.join(GOLDEN, "lsb*.npz"))))
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "*.npz"))))
 def test_parity_vs_golden_fixture(T, path):
     g = np.load(path, allow_pickle=False)
     kw = {k: (float(v) if "." in v else int(v)) for k, v in g["params"]}
     got, _ = gpu_run(T, kw, g["nco"], g["I"], g["Q"])
     err = siggen.block_rel_err(got, g["audio"], L)
-    assert err.max() <= TOL, err
+    assert err.max() <= (AM_TOL if kw["mode"] == 2 else TOL), err
+
+
+def test_parity_nfm(T):
+    """BASELINE config 3's demodulator as the firmware actually runs it: quadri-
+    correlator + limiter + real overlap-save audio filter, dec filters redesigned for 12 kHz"""
+    nch, nfr = 32, 6
+    nco = siggen.nco_grid(nch, seed=13)
+    nco[:3] = [0, 40000, -43000]
+    kw = dict(mode=3, FLoCut=200, FHiCut=3000, nfmFilterBW=12000)
+    I, Q = siggen.make_fm(nch, nfr * L, nco)
+    got, _ = gpu_run(T, kw, nco, I, Q)
+    ref = oracle_run(kw, nco, I, Q)
+    err = siggen.block_rel_err(got, ref, L)
+    assert err.max() <= TOL, (err.max(), np.unravel_index(err.argmax(), err.shape))
+    # frame-by-frame == one call (the discriminator's odd "last sample" state included)
+    split, _ = gpu_run(T, kw, nco, I, Q, split=[k * L for k in range(nfr + 1)])
+    assert np.array_equal(got, split)
+
+
+# AM: the reference's DC remover w = |z| + 0.99 w_old accumulates ~100x the signal in f32, so the
+# ORACLE itself sits ~1e-5 (block-relative) away from an exact evaluation of the same formula
+# (tests/test_oracle_vs_f64.py measures that floor).  Two f32 evaluations with inputs that differ
+# in the last bit decorrelate at that level, so 1e-5 vs the oracle is not attainable by any
+# implementation; the GPU runs this scan in f64 and is held to 5e-5.
+
+
+def test_parity_am(T):
+    nch, nfr = 32, 6
+    nco = siggen.nco_grid(nch, seed=17)
+    kw = dict(mode=2, FLoCut=-3000, FHiCut=3000)
+    I, Q = siggen.make_iq(nch, nfr * L, nco, mode=2, seed=31)
+    got, _ = gpu_run(T, kw, nco, I, Q)
+    ref = oracle_run(kw, nco, I, Q)
+    err = siggen.block_rel_err(got, ref, L)
+    assert err.max() <= AM_TOL, (err.max(), np.unravel_index(err.argmax(), err.shape))
+    split, _ = gpu_run(T, kw, nco, I, Q, split=[0, L, 3 * L, nfr * L])
+    assert np.array_equal(got, split)
 
 
 def test_streaming_split_is_bit_identical(T):
@@ -206,7 +243,7 @@ def test_argument_errors(T):
     with pytest.raises(T.T41RxError) as e:
         rx.SetNCOFreq(np.full(4, 200000))
     assert e.value.status == _lib.ERR_ARG
-    for unsupported in (dict(AGCMode=1), dict(mode=2, FLoCut=-3000, FHiCut=3000), dict(mode=3)):
+    for unsupported in (dict(AGCMode=1), dict(fft_length=4096, FLoCut=400, FHiCut=600)):
         with pytest.raises(T.T41RxError) as e:
             T.RxChain(4, T.default_params(**unsupported))
         assert e.value.status == _lib.ERR_UNSUPPORTED

@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 import t41_sdr_amd as T  # noqa: E402
 
 FS = 192000.0
-N_CHANNELS = 4096          # BASELINE.json: batch=4096
+N_CHANNELS = int(os.environ.get("T41RX_BENCH_NCH", "4096"))  # BASELINE.json: batch=4096 (env override: scaling experiments only)
 FFT_LENGTH = 512
 FRAME_LEN = 4 * FFT_LENGTH  # 2048 complex samples per channel per step
 BYTES_PER_SAMPLE = 12.0     # 2 x f32 in + 1 x f32 out per input complex sample

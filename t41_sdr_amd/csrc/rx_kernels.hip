@@ -299,7 +299,10 @@ constexpr int kLdsTabFloats = 2 * (512 + 448 + 56);                          // 
 constexpr int kXFloats = 1352;  // 2 * (xpad(539) + 1) = 1348, rounded to 16 B
 constexpr int kY1Floats = 608;  // 304 complex
 constexpr int kX = 0, kY1 = kXFloats;
-constexpr int kLdsFloatsPerWave = kXFloats + kY1Floats;  // 1960 floats = 7840 B
+// 2052 floats = 8208 B: X + Y1 (1960) rounded up so the whole slice can double as the 2048-float
+// output transposition buffer; tables + 4 slices = exactly the 40 KiB the launch requests
+constexpr int kLdsFloatsPerWave = 2052;
+static_assert(kXFloats + kY1Floats <= kLdsFloatsPerWave && kLdsFloatsPerWave >= 2048, "slice too small");
 static_assert(kXFloats >= 8 * kFftRow * 2, "FFT exchange buffer must fit in X");
 __device__ __forceinline__ constexpr int xpad(int j) { return j + ((j >> 3) << 1); }  // complex units
 
@@ -939,6 +942,11 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
       }
       // out[4n + j - 1] = sum_t state[n + t] * c[(4 - j) + 4 t],  state[n + t] = w[u + t]:
       // (out[4n], out[4n+1]) += w * (c[4t+3], c[4t+2]);  (out[4n+2], out[4n+3]) += w * (c[4t+1], c[4t])
+      // A lane owns 32 consecutive output samples (128 B).  Storing them directly would be 8
+      // instructions of 64 scattered 16-byte pieces each (2 M partial-line writes per launch), so
+      // each float4 goes to an XOR-swizzled LDS slot first (slot 8 lane + (u ^ (lane & 7)):
+      // conflict-free both for these row writes and for the column reads below) ...
+      wave_sync();
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         f2 o01 = splat(0.0f), o23 = splat(0.0f);
@@ -948,10 +956,19 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
           o01 = pk_fma(x, f2{c4[4 * t + 3], c4[4 * t + 2]}, o01);
           o23 = pk_fma(x, f2{c4[4 * t + 1], c4[4 * t]}, o23);
         }
-        // ---- volume (Process.cpp:929) and store
+        // ---- volume (Process.cpp:929)
         o01 *= splat(out_scale);
         o23 *= splat(out_scale);
-        *reinterpret_cast<float4 *>(gO + 32 * lane + 4 * u) = make_float4(o01.x, o01.y, o23.x, o23.y);
+        *reinterpret_cast<float4 *>(lds + 4 * (8 * lane + (u ^ (lane & 7)))) = make_float4(o01.x, o01.y, o23.x, o23.y);
+      }
+      wave_sync();
+      // ... and every global store instruction then writes 1 KiB of consecutive addresses:
+      // float4 index F = 64 i + lane lives in row F >> 3 = 8 i + (lane >> 3), column lane & 7
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int row = 8 * i + (lane >> 3);
+        const float4 t = lds4(lds + 4 * (8 * row + ((lane & 7) ^ (row & 7))));
+        *reinterpret_cast<float4 *>(gO + 256 * i + 4 * lane) = t;
       }
     }
   }  // frames

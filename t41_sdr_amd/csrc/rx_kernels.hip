@@ -394,10 +394,15 @@ constexpr int kModeSsb = 0, kModeAm = 1, kModeNfm = 2;  // kernel template MODE
 // ------------------------------------------------------------------------------------------
 // The fused kernel, FFT_LENGTH = 512
 // ------------------------------------------------------------------------------------------
-template <int MODE, bool DEBUG>
+// PART 0: the whole chain for FFT_LENGTH 512.  PART 1 / PART 2 are the two ends of the
+// FFT_LENGTH 4096 pipeline (front: loads .. /8 decimation + level adjust -> `mid`; back:
+// `aud24` -> interpolators -> store): a 16384-sample frame is 8 consecutive 2048-sample segments
+// for them, the 4096-point fast convolution in between is fastconv4096_kernel.
+template <int MODE, bool DEBUG, int PART>
 __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int L = 2048, D = 256, N = 512;
+  constexpr int kStateN = (PART == 0) ? 512 : 4096;  // per-channel state record size follows fft_length
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ch = blockIdx.x * 4 + wv;
@@ -419,7 +424,7 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
 
   const cf *ltab = reinterpret_cast<const cf *>(smem);
   float *lds = smem + kLdsTabFloats + wv * kLdsFloatsPerWave;
-  float *st = a.state + (size_t)(T41RX_ABLATE == 9 ? (ch & 15) : ch) * state_floats(N);
+  float *st = a.state + (size_t)(T41RX_ABLATE == 9 ? (ch & 15) : ch) * state_floats(kStateN);
   // coefficients are read-only for the kernel: constant address space -> scalar (SMEM) loads,
   // re-derived through an opaque asm per phase so the compiler keeps the tap loads next to
   // their use instead of hoisting all 180 of them (and spilling SGPRs).
@@ -439,441 +444,464 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
     transient = fabs(osc_r * osc_r - rs) > 1e-13;
   }
 
+  f2 dc2 = splat(0.0f);  // DC high-pass carries, see below
   for (int f = 0; f < a.nframes; ++f) {
     const size_t fbase = ((size_t)(T41RX_ABLATE == 9 ? (ch & 15) : ch) * a.nframes + f) * L;
     const float *__restrict__ gI = a.I + fbase;
     const float *__restrict__ gQ = a.Q + fbase;
     float *__restrict__ gO = a.out + fbase;
 
-    // ---- first loads of the frame
-    float4 nI0 = *reinterpret_cast<const float4 *>(gI + 8 * lane);
-    float4 nI1 = *reinterpret_cast<const float4 *>(gI + 8 * lane + 4);
-    float4 nQ0 = *reinterpret_cast<const float4 *>(gQ + 8 * lane);
-    float4 nQ1 = *reinterpret_cast<const float4 *>(gQ + 8 * lane + 4);
-    const float4 tailI = *reinterpret_cast<const float4 *>(gI + (L - 256) + 4 * lane);
-
-    // ---- delay lines HBM -> LDS (every frame is self-contained: load state, run, store state)
-    wave_sync();
-    if (lane < 14)
-      *reinterpret_cast<float4 *>(lds + kX + 2 * xpad(2 * lane)) = *reinterpret_cast<const float4 *>(st + kStDec1 + 4 * lane);
-    if (lane < 24)
-      *reinterpret_cast<float4 *>(lds + kY1 + 4 * lane) = *reinterpret_cast<const float4 *>(st + kStDec2 + 4 * lane);
-
-    // gains (Process.cpp:117-134, 165-166).  g_band and -IQAmp are folded into one factor on I
-    // (exact whenever either is +-1, which is the firmware default; one rounding otherwise)
-    float g_rf, iq_phase;
-    f2 g_iq;
-    bool unit_gain;
-    {
-      const CoefPtr c = fresh_coef(cf0);
-      g_rf = c->sc[kScRfGain];
-      const float gb = c->sc[kScBandGain];
-      const bool iq_on = c->sc[kScIqCorrOn] != 0.0f;
-      g_iq = f2{iq_on ? gb * c->sc[kScNegIqAmp] : gb, gb};
-      unit_gain = (g_iq.x == 1.0f) && (g_iq.y == 1.0f);
-      iq_phase = iq_on ? c->sc[kScIqPhase] : 0.0f;
-    }
-
-    // ---- Q's DC-block start state = state after ALL of this frame's I (one shared biquad
-    // instance runs over I then Q, Process.cpp:127-128).  a1^256 ~ 3e-18, so the last 256 I
-    // samples decide it.
-    f2 dc2;  // (carry of the I chain, carry of the Q chain)
-    {
-      const float x[4] = {tailI.x * g_rf, tailI.y * g_rf, tailI.z * g_rf, tailI.w * g_rf};
-      dc2 = f2{dc_carry, dc_highpass_end_state<4>(x, hp4.x, hp4.y)};
-    }
-
-    cf y2[2][2];  // /8 outputs of this frame: m = 128*round + 2*lane + e
-    cf v[8];      // FFT registers; v[0..3] = previous block, prefetched below
-
+    float aud[4];                            // 4 demodulated samples @24 kS/s: i = lane + 64 j (AM: 4 lane + j)
+    float4 hist1 = make_float4(0, 0, 0, 0);  // x2 interpolator history (lanes 0..5)
+    float hist2 = 0.0f;                      // x4 interpolator history (lane i = entry i)
+    if (PART == 2) {
+      // back half of the 4096 pipeline: this segment's 256 audio samples come from the
+      // fast-convolution kernel
+      const float *au = a.aud24 + ((size_t)ch * a.nframes + f) * D;
 #pragma unroll
-    for (int rd = 0; rd < 2; ++rd) {
-#pragma unroll 1
-      for (int h = 0; h < 2; ++h) {
-        const int s = 2 * rd + h;
-        // -- RF gain (Process.cpp:117-119); the multiply also interleaves I and Q into pairs
-        cf z[8];
-        z[0] = cf{nI0.x * g_rf, nQ0.x * g_rf};
-        z[1] = cf{nI0.y * g_rf, nQ0.y * g_rf};
-        z[2] = cf{nI0.z * g_rf, nQ0.z * g_rf};
-        z[3] = cf{nI0.w * g_rf, nQ0.w * g_rf};
-        z[4] = cf{nI1.x * g_rf, nQ1.x * g_rf};
-        z[5] = cf{nI1.y * g_rf, nQ1.y * g_rf};
-        z[6] = cf{nI1.z * g_rf, nQ1.z * g_rf};
-        z[7] = cf{nI1.w * g_rf, nQ1.w * g_rf};
-        if (s < 3) {  // prefetch the next sub-block
-          const int o = 512 * (s + 1) + (T41RX_CUT(8) ? 4 : 8) * lane;
-          const int o2 = T41RX_CUT(8) ? 256 : 4;
-          nI0 = *reinterpret_cast<const float4 *>(gI + o);
-          nI1 = *reinterpret_cast<const float4 *>(gI + o + o2);
-          nQ0 = *reinterpret_cast<const float4 *>(gQ + o);
-          nQ1 = *reinterpret_cast<const float4 *>(gQ + o + o2);
-        } else {  // last sub-block: prefetch the overlap-save "previous" block instead
-          const cf *ov = reinterpret_cast<const cf *>(st + kStOverlap);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = ov[64 * j + lane];
-        }
-        // -- DC high-pass (127-128), band gain (133-134) / IQ amplitude (166)
-        if (!T41RX_CUT(6)) dc_highpass<8>(z, dc2, lane, hp8.x, hp8.y);
-        if (!unit_gain) {
-#pragma unroll
-          for (int k = 0; k < 8; ++k) z[k] *= g_iq;
-        }
-        // -- IQ phase correction (Utility.cpp:178-187)
-        if (iq_phase < 0.0f) {
-#pragma unroll
-          for (int k = 0; k < 8; ++k) z[k].y = fmaf(iq_phase, z[k].x, z[k].y);
-        } else if (iq_phase > 0.0f) {
-#pragma unroll
-          for (int k = 0; k < 8; ++k) z[k].x = fmaf(iq_phase, z[k].y, z[k].x);
-        }
-        // -- oscillator for my 8 samples.  Osc_n = V_n * W has phase phase0 + (n+1) dphi.
-        const int n0 = 512 * s + 8 * lane;
-        float amp[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) amp[k] = 1.0f;
-        if (transient) {
-          // start-up of the amplitude loop g = 1.95 - |V|^2 (Freq_Shift.cpp:130-134): replay the
-          // scalar recurrence (wave-uniform); each lane keeps its own 8 values.  |Osc_n| / A* =
-          // |V_n| / r*.
-          const NcoPtr nt = fresh_nco(nco);
-          const double r_star_sq = uniform_f64(nt->r_star_sq);
-          const double w_abs = uniform_f64(nt->w_abs);
-          const double inv_r = 1.0 / sqrt(r_star_sq);
-          double r = osc_r;
-          for (int g = 0; g < 64; ++g) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-              if (g == lane) amp[k] = (float)(r * inv_r);
-              r = r * (1.95 - r * r) * w_abs;
-            }
-            if (fabs(r * r - r_star_sq) <= 1e-13) break;
-          }
-          osc_r = r;
-        }
-        cf base;
-        {
-          const uint64_t P = phase0 + (uint64_t)(n0 + 1) * dphi;
-          const float2 t = tab[kTabSinCos + (int)(P >> 56)];
-          const uint32_t u = (uint32_t)(P >> 24);
-          const float ang = (float)u * (float)(6.283185307179586476925 / 256.0 / 4294967296.0);
-          const float a2 = ang * ang;
-          const float sn = ang * fmaf(a2, -1.0f / 6.0f, 1.0f);
-          const float cs = fmaf(a2, fmaf(a2, 1.0f / 24.0f, -0.5f), 1.0f);
-          base = cmul(cf{t.x, t.y}, cf{cs, sn});
-        }
-        // -- Fs/4 shift (x j^n, Freq_Shift.cpp:42-65) and NCO mix (Freq_Shift.cpp:138-139):
-        //    (I' + jQ') = (I + jQ) j^k conj(Osc_k) = (I + jQ) conj(base wk''),  wk'' = wk (-j)^k
-        //    (the host pre-rotates the per-channel constants, so the Fs/4 shift costs nothing)
-        const NcoPtr ncw = fresh_nco(nco);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const cf w = cf{ncw->wk[k][0], ncw->wk[k][1]};
-          if (T41RX_CUT(5)) continue;
-          cf osc = cmul_s(base, w);
-          if (transient) osc *= splat(amp[k]);
-          z[k] = cmulc(z[k], osc);
-        }
-        if (transient) {
-          const double rs = uniform_f64(fresh_nco(nco)->r_star_sq);
-          transient = fabs(osc_r * osc_r - rs) > 1e-13;
-        }
-        if (DEBUG && a.dbg_nco) {
-          float *dn = a.dbg_nco + ((size_t)ch * a.nframes + f) * (2 * L);
-#pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            dn[n0 + k] = z[k].x;
-            dn[L + n0 + k] = z[k].y;
-          }
-        }
-        // -- stage into LDS, then decimate by 4 (28 taps): outputs m = 2*lane, 2*lane+1
-        wave_sync();
-        float *xw = lds + kX + 20 * lane;  // lane stride: 8 complex + 1 pad slot = 20 floats
-#pragma unroll
-        for (int i = 0; i < 4; ++i)  // logical 28 + 8 lane + 2 i  ->  xpad() - 10 lane is a constant
-          *reinterpret_cast<float4 *>(xw + 2 * (xpad(28 + 2 * i))) =
-              make_float4(z[2 * i].x, z[2 * i].y, z[2 * i + 1].x, z[2 * i + 1].y);
-        wave_sync();
-        cf o1[2];
-        // arm_fir_decimate_f32: y[m] = sum_i c[i] * state[4m + i]; state[i] = buf[i + 1]
-        {
-          auto pidx = [](int o) { return xpad(o); };  // window-relative, identical for every lane
-          if (!T41RX_CUT(4)) {
-            fir_pair<kDec1Taps, 1, 5, 18, 6>(xw, pidx, (CFloatPtr)cf0->dec1, o1[0], o1[1]);
-          } else {
-            o1[0] = *reinterpret_cast<cf *>(xw);
-            o1[1] = *reinterpret_cast<cf *>(xw + 8);
-          }
-        }
-        // -- roll the /4 history (logical 512..539 -> 0..27) and append the /4 outputs
-        {
-          float4 hh = make_float4(0, 0, 0, 0);
-          if (lane < 14) hh = lds4(lds + kX + 2 * xpad(512 + 2 * lane));
-          wave_sync();
-          if (lane < 14) *reinterpret_cast<float4 *>(lds + kX + 2 * xpad(2 * lane)) = hh;
-          *reinterpret_cast<float4 *>(lds + kY1 + 2 * (48 + 128 * h + 2 * lane)) =
-              make_float4(o1[0].x, o1[0].y, o1[1].x, o1[1].y);
-        }
-      }  // h
-      // ---- decimate by 2 (46 taps) over the 256 new /4 samples: m = 2*lane, 2*lane+1
-      wave_sync();
-      // y[m] = sum_i c[i] * state[2m + i]; state[i] = buf[i + 3]
-      {
-        auto lin = [](int o) { return o; };
-        if (!T41RX_CUT(3)) {
-          fir_pair<kDec2Taps, 3, 5, 26, 6>(lds + kY1 + 8 * lane, lin, (CFloatPtr)cf0->dec2, y2[rd][0], y2[rd][1]);
-        } else {
-          y2[rd][0] = *reinterpret_cast<cf *>(lds + kY1 + 8 * lane);
-          y2[rd][1] = *reinterpret_cast<cf *>(lds + kY1 + 8 * lane + 2);
-        }
-      }
-      {  // roll the /2 history: logical 256..303 -> 0..47
-        float4 hh = make_float4(0, 0, 0, 0);
-        if (lane < 24) hh = lds4(lds + kY1 + 2 * (256 + 2 * lane));
-        wave_sync();
-        if (lane < 24) *reinterpret_cast<float4 *>(lds + kY1 + 4 * lane) = hh;
-      }
-    }  // rd
-    phase0 += (uint64_t)L * dphi;
-    dc_carry = uniform_f32(dc2.y);  // the shared biquad ends the frame on Q
-
-    // ---- delay lines back to HBM (the LDS copies are about to be reused as scratch); issue
-    // the small back-end history loads now so the FFT hides their latency
-    wave_sync();
-    if (lane < 14) *reinterpret_cast<float4 *>(st + kStDec1 + 4 * lane) = lds4(lds + kX + 2 * xpad(2 * lane));
-    if (lane < 24) *reinterpret_cast<float4 *>(st + kStDec2 + 4 * lane) = lds4(lds + kY1 + 4 * lane);
-    float4 hist1 = make_float4(0, 0, 0, 0);
-    if (lane < 6) hist1 = *reinterpret_cast<const float4 *>(st + kStInt1 + 4 * lane);
-    float hist2 = 0.0f;
-    if (lane < 8) hist2 = st[kStInt2 + lane];
-    wave_sync();
-
-    // ---- level adjust (Process.cpp:481-492)
-    const float level = fresh_coef(cf0)->sc[kScLevel];
-#pragma unroll
-    for (int rd = 0; rd < 2; ++rd)
-#pragma unroll
-      for (int e = 0; e < 2; ++e) y2[rd][e] *= splat(level);
-    if (DEBUG && a.dbg_dec) {
-      float *dd = a.dbg_dec + ((size_t)ch * a.nframes + f) * N;
-#pragma unroll
-      for (int rd = 0; rd < 2; ++rd)
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          dd[128 * rd + 2 * lane + e] = y2[rd][e].x;
-          dd[D + 128 * rd + 2 * lane + e] = y2[rd][e].y;
-        }
-    }
-
-    // ---- NFM (Process.cpp:716-727): quadri-correlator discriminator on the 256 new complex
-    // samples, hard limiter, then the demodulated REAL audio goes through the same overlap-save
-    // filter with zero imaginary part (Process.cpp:765-816)
-    if (MODE == kModeNfm) {
-      // fmdemod_quadri_K (Demod.h:7) is a double: K * (float expr) / (float expr) in double
-      constexpr double K = 0.340447550238101026565118445432744920253753662109375;
-      const cf *ms = reinterpret_cast<const cf *>(st + kStMisc + kMiscNfmI);
-      const cf last = ms[0];  // nfmdemod()'s "last sample", see the quirk note below
-      float au[2][2];
-#pragma unroll
-      for (int rd = 0; rd < 2; ++rd) {
-        // previous complex sample of m = 128 rd + 2 lane: lane-1's odd sample; lane 0 wraps to the
-        // previous round's last sample
-        cf prev0 = cf{lane_up1(y2[rd][1].x), lane_up1(y2[rd][1].y)};
-        if (rd == 1 && lane == 0)
-          prev0 = cf{__int_as_float(__builtin_amdgcn_readlane(__float_as_int(y2[0][1].x), 63)),
-                     __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y2[0][1].y), 63))};
-        const cf cur0 = y2[rd][0], cur1 = y2[rd][1];
-        // Demod.cpp:229-231: (qnow * ilast - inow * qlast) / (inow^2 + qnow^2)
-        float num0 = cur0.y * prev0.x - cur0.x * prev0.y;
-        const float den0 = cur0.x * cur0.x + cur0.y * cur0.y;
-        const float num1 = cur1.y * cur0.x - cur1.x * cur0.y;
-        const float den1 = cur1.x * cur1.x + cur1.y * cur1.y;
-        if (rd == 0 && lane == 0)  // Demod.cpp:224: first sample of the frame uses the difference form
-          num0 = cur0.x * (cur0.y - last.y) - cur0.y * (cur0.x - last.x);
-        float a0 = (float)(K * (double)num0 / (double)den0);
-        float a1 = (float)(K * (double)num1 / (double)den1);
-        // Process.cpp:719-727: limiter, skips sample 0 of the frame
-        if (!(rd == 0 && lane == 0)) {
-          a0 = (1.0f < a0) ? 1.0f : a0;
-          a0 = (-1.0f > a0) ? -1.0f : a0;
-        }
-        a1 = (1.0f < a1) ? 1.0f : a1;
-        a1 = (-1.0f > a1) ? -1.0f : a1;
-        au[rd][0] = a0;
-        au[rd][1] = a1;
-      }
-      // Demod.cpp:232-233 keeps floats [input_size-2], [input_size-1] of the interleaved buffer
-      // as "last sample": that is complex sample 127 (m = 127: round 0, lane 63, odd), not 255
-      if (lane == 63) *reinterpret_cast<cf *>(st + kStMisc + kMiscNfmI) = y2[0][1];
-#pragma unroll
-      for (int rd = 0; rd < 2; ++rd)
-#pragma unroll
-        for (int e = 0; e < 2; ++e) y2[rd][e] = cf{au[rd][e], 0.0f};
-    }
-
-    // ---- overlap-save assemble (Process.cpp:498-522): v[0..3] = previous block, v[4..7] = new
-    {
-      cf *tb = reinterpret_cast<cf *>(lds);
-#pragma unroll
-      for (int rd = 0; rd < 2; ++rd)
-        *reinterpret_cast<float4 *>(lds + 2 * (128 * rd + 2 * lane)) =
-            make_float4(y2[rd][0].x, y2[rd][0].y, y2[rd][1].x, y2[rd][1].y);
-      wave_sync();
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[4 + j] = tb[lane + 64 * j];
-      cf *ov = reinterpret_cast<cf *>(st + kStOverlap);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) ov[64 * j + lane] = v[4 + j];
-    }
-
-    // ---- FFT, x mask, inverse FFT (Process.cpp:535-595).  The mask table is pre-scaled by 1/N.
-    {
-      cf tw1[7], tw2[7];
-#pragma unroll
-      for (int q = 0; q < 7; ++q) {
-        tw1[q] = ltab[kLdsTabTw1 + 64 * q + lane];
-        tw2[q] = ltab[kLdsTabTw2 + 8 * q + (lane & 7)];
-      }
-      if (!T41RX_CUT(2)) {
-        fft512<false>(v, tw1, tw2, lds, lane);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = cmul(v[r], ltab[kLdsTabMask + 64 * r + lane]);
-        fft512<true>(v, tw1, tw2, lds, lane);
-      }
-    }
-
-    // ---- AGC off: fixed gain on the valid half (DSP_Fn.cpp:494-502); SSB/NFM: audio = Re
-    float aud[4];
-    const float fixed_gain = fresh_coef(cf0)->sc[kScFixedGain];
-    if (MODE != kModeAm) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) aud[j] = fixed_gain * v[4 + j].x;
+      for (int j = 0; j < 4; ++j) aud[j] = au[lane + 64 * j];
+      if (lane < 6) hist1 = *reinterpret_cast<const float4 *>(st + kStInt1 + 4 * lane);
+      if (lane < 8) hist2 = st[kStInt2 + lane];
     } else {
-      // ---- AM (Process.cpp:697-707): AlphaBetaMag envelope (Utility.cpp:269-285), DC removal
-      // w = m + 0.99 w_old, y = w - w_old, then biquad_lowpass1 (DF1).  Both recurrences run as
-      // wave scans over lane-contiguous chunks of 4 samples.
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const cf g = v[4 + j] * splat(fixed_gain);
-        const float ai = fabsf(g.x), aq = fabsf(g.y);
-        const float hi = fmaxf(ai, aq), lo = fminf(ai, aq);
-        aud[j] = 0.960433870103f * hi + 0.397824734759f * lo;
-      }
+      // ---- first loads of the frame
+      float4 nI0 = *reinterpret_cast<const float4 *>(gI + 8 * lane);
+      float4 nI1 = *reinterpret_cast<const float4 *>(gI + 8 * lane + 4);
+      float4 nQ0 = *reinterpret_cast<const float4 *>(gQ + 8 * lane);
+      float4 nQ1 = *reinterpret_cast<const float4 *>(gQ + 8 * lane + 4);
+      const float4 tailI = *reinterpret_cast<const float4 *>(gI + (L - 256) + 4 * lane);
+
+      // ---- delay lines HBM -> LDS (every frame is self-contained: load state, run, store state)
       wave_sync();
-#pragma unroll
-      for (int j = 0; j < 4; ++j) lds[24 + lane + 64 * j] = aud[j];
-      wave_sync();
-      const float4 m4 = lds4(lds + 24 + 4 * lane);
-      const float m[4] = {m4.x, m4.y, m4.z, m4.w};
-      float *ms = st + kStMisc;
-      // -- DC block.  The reference accumulates w ~ 100x the signal in f32; here the scan runs in
-      // f64 (no accumulation noise of its own), state kept as the reference's float wold
-      const double ca = (double)0.99f;
-      double wl[4];
-      {
-        double wprev = (lane == 0) ? (double)ms[kMiscWold] : 0.0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          wprev = (double)m[k] + ca * wprev;
-          wl[k] = wprev;
-        }
-      }
-      double B = wl[3];
-      {
-        const double a4 = ca * ca * ca * ca, a8 = a4 * a4, a16 = a8 * a8, a32 = a16 * a16;
-        double p15 = a4, p31 = a4;  // ca^(4 ((lane&15)+1)), ca^(4 ((lane&31)+1))
-        for (int i = 0; i < (lane & 15); ++i) p15 *= a4;
-        for (int i = 0; i < (lane & 31); ++i) p31 *= a4;
-        B = fma(a4, dpp_d<kDppRowShr1, 0xf, true>(B), B);
-        B = fma(a8, dpp_d<kDppRowShr2, 0xf, true>(B), B);
-        B = fma(a16, dpp_d<kDppRowShr4, 0xf, true>(B), B);
-        B = fma(a32, dpp_d<kDppRowShr8, 0xf, true>(B), B);
-        B = fma(p15, dpp_d<kDppRowBcast15, 0xa, false>(B), B);
-        B = fma(p31, dpp_d<kDppRowBcast31, 0xc, false>(B), B);
-        const double e = dpp_d<kDppWaveShr1, 0xf, true>(B);  // w just before my first sample (lane 0: already included)
-        double wk_prev = (lane == 0) ? (double)ms[kMiscWold] : e;
-        double apow = ca;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const double wt = (lane == 0) ? wl[k] : wl[k] + apow * e;
-          aud[k] = (float)(wt - wk_prev);
-          wk_prev = wt;
-          apow *= ca;
-        }
-        if (lane == 63) ms[kMiscWold] = (float)wk_prev;
-      }
-      // -- biquad_lowpass1, DF1: y = b0 x + b1 x1 + b2 x2 + a1 y1 + a2 y2 (a's pre-negated)
+      if (lane < 14)
+        *reinterpret_cast<float4 *>(lds + kX + 2 * xpad(2 * lane)) = *reinterpret_cast<const float4 *>(st + kStDec1 + 4 * lane);
+      if (lane < 24)
+        *reinterpret_cast<float4 *>(lds + kY1 + 4 * lane) = *reinterpret_cast<const float4 *>(st + kStDec2 + 4 * lane);
+
+      // gains (Process.cpp:117-134, 165-166).  g_band and -IQAmp are folded into one factor on I
+      // (exact whenever either is +-1, which is the firmware default; one rounding otherwise)
+      float g_rf, iq_phase;
+      f2 g_iq;
+      bool unit_gain;
       {
         const CoefPtr c = fresh_coef(cf0);
-        const float b0 = c->lp1[0], b1 = c->lp1[1], b2 = c->lp1[2], a1 = c->lp1[3], a2 = c->lp1[4];
-        const float4 sv = *reinterpret_cast<const float4 *>(ms + kMiscLp1);  // x1, x2, y1, y2
-        float xm1 = lane_up1(aud[3]), xm2 = lane_up1(aud[2]);
-        if (lane == 0) {
-          xm1 = sv.x;
-          xm2 = sv.y;
-        }
-        float y[4];
-        float s1 = (lane == 0) ? sv.z : 0.0f, s2 = (lane == 0) ? sv.w : 0.0f;  // y[n-1], y[n-2]
+        g_rf = c->sc[kScRfGain];
+        const float gb = c->sc[kScBandGain];
+        const bool iq_on = c->sc[kScIqCorrOn] != 0.0f;
+        g_iq = f2{iq_on ? gb * c->sc[kScNegIqAmp] : gb, gb};
+        unit_gain = (g_iq.x == 1.0f) && (g_iq.y == 1.0f);
+        iq_phase = iq_on ? c->sc[kScIqPhase] : 0.0f;
+      }
+
+      // ---- Q's DC-block start state = state after ALL of this frame's I (one shared biquad
+      // instance runs over I then Q, Process.cpp:127-128).  a1^256 ~ 3e-18, so the last 256 I
+      // samples decide it.
+      // (carry of the I chain, carry of the Q chain).  One biquad instance filters the whole
+      // frame's I and then its Q (Process.cpp:127-128): for the 4096 pipeline a frame is 8
+      // segments, so the I chain runs on across segments and the Q chain starts from the state
+      // after the frame's LAST I samples.
+      if (PART == 0 || (f & 7) == 0) {
+        const float4 tailF = (PART == 0) ? tailI : *reinterpret_cast<const float4 *>(gI + (8 * L - 256) + 4 * lane);
+        const float x[4] = {tailF.x * g_rf, tailF.y * g_rf, tailF.z * g_rf, tailF.w * g_rf};
+        dc2 = f2{dc_carry, dc_highpass_end_state<4>(x, hp4.x, hp4.y)};
+      }
+
+      cf y2[2][2];  // /8 outputs of this frame: m = 128*round + 2*lane + e
+      cf v[8];      // FFT registers; v[0..3] = previous block, prefetched below
+
+  #pragma unroll
+      for (int rd = 0; rd < 2; ++rd) {
+  #pragma unroll 1
+        for (int h = 0; h < 2; ++h) {
+          const int s = 2 * rd + h;
+          // -- RF gain (Process.cpp:117-119); the multiply also interleaves I and Q into pairs
+          cf z[8];
+          z[0] = cf{nI0.x * g_rf, nQ0.x * g_rf};
+          z[1] = cf{nI0.y * g_rf, nQ0.y * g_rf};
+          z[2] = cf{nI0.z * g_rf, nQ0.z * g_rf};
+          z[3] = cf{nI0.w * g_rf, nQ0.w * g_rf};
+          z[4] = cf{nI1.x * g_rf, nQ1.x * g_rf};
+          z[5] = cf{nI1.y * g_rf, nQ1.y * g_rf};
+          z[6] = cf{nI1.z * g_rf, nQ1.z * g_rf};
+          z[7] = cf{nI1.w * g_rf, nQ1.w * g_rf};
+          if (s < 3) {  // prefetch the next sub-block
+            const int o = 512 * (s + 1) + (T41RX_CUT(8) ? 4 : 8) * lane;
+            const int o2 = T41RX_CUT(8) ? 256 : 4;
+            nI0 = *reinterpret_cast<const float4 *>(gI + o);
+            nI1 = *reinterpret_cast<const float4 *>(gI + o + o2);
+            nQ0 = *reinterpret_cast<const float4 *>(gQ + o);
+            nQ1 = *reinterpret_cast<const float4 *>(gQ + o + o2);
+          } else {  // last sub-block: prefetch the overlap-save "previous" block instead
+            const cf *ov = reinterpret_cast<const cf *>(st + kStOverlap);
+  #pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = ov[64 * j + lane];
+          }
+          // -- DC high-pass (127-128), band gain (133-134) / IQ amplitude (166)
+          if (!T41RX_CUT(6)) dc_highpass<8>(z, dc2, lane, hp8.x, hp8.y);
+          if (!unit_gain) {
+  #pragma unroll
+            for (int k = 0; k < 8; ++k) z[k] *= g_iq;
+          }
+          // -- IQ phase correction (Utility.cpp:178-187)
+          if (iq_phase < 0.0f) {
+  #pragma unroll
+            for (int k = 0; k < 8; ++k) z[k].y = fmaf(iq_phase, z[k].x, z[k].y);
+          } else if (iq_phase > 0.0f) {
+  #pragma unroll
+            for (int k = 0; k < 8; ++k) z[k].x = fmaf(iq_phase, z[k].y, z[k].x);
+          }
+          // -- oscillator for my 8 samples.  Osc_n = V_n * W has phase phase0 + (n+1) dphi.
+          const int n0 = 512 * s + 8 * lane;
+          float amp[8];
+  #pragma unroll
+          for (int k = 0; k < 8; ++k) amp[k] = 1.0f;
+          if (transient) {
+            // start-up of the amplitude loop g = 1.95 - |V|^2 (Freq_Shift.cpp:130-134): replay the
+            // scalar recurrence (wave-uniform); each lane keeps its own 8 values.  |Osc_n| / A* =
+            // |V_n| / r*.
+            const NcoPtr nt = fresh_nco(nco);
+            const double r_star_sq = uniform_f64(nt->r_star_sq);
+            const double w_abs = uniform_f64(nt->w_abs);
+            const double inv_r = 1.0 / sqrt(r_star_sq);
+            double r = osc_r;
+            for (int g = 0; g < 64; ++g) {
+  #pragma unroll
+              for (int k = 0; k < 8; ++k) {
+                if (g == lane) amp[k] = (float)(r * inv_r);
+                r = r * (1.95 - r * r) * w_abs;
+              }
+              if (fabs(r * r - r_star_sq) <= 1e-13) break;
+            }
+            osc_r = r;
+          }
+          cf base;
+          {
+            const uint64_t P = phase0 + (uint64_t)(n0 + 1) * dphi;
+            const float2 t = tab[kTabSinCos + (int)(P >> 56)];
+            const uint32_t u = (uint32_t)(P >> 24);
+            const float ang = (float)u * (float)(6.283185307179586476925 / 256.0 / 4294967296.0);
+            const float a2 = ang * ang;
+            const float sn = ang * fmaf(a2, -1.0f / 6.0f, 1.0f);
+            const float cs = fmaf(a2, fmaf(a2, 1.0f / 24.0f, -0.5f), 1.0f);
+            base = cmul(cf{t.x, t.y}, cf{cs, sn});
+          }
+          // -- Fs/4 shift (x j^n, Freq_Shift.cpp:42-65) and NCO mix (Freq_Shift.cpp:138-139):
+          //    (I' + jQ') = (I + jQ) j^k conj(Osc_k) = (I + jQ) conj(base wk''),  wk'' = wk (-j)^k
+          //    (the host pre-rotates the per-channel constants, so the Fs/4 shift costs nothing)
+          const NcoPtr ncw = fresh_nco(nco);
+  #pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const cf w = cf{ncw->wk[k][0], ncw->wk[k][1]};
+            if (T41RX_CUT(5)) continue;
+            cf osc = cmul_s(base, w);
+            if (transient) osc *= splat(amp[k]);
+            z[k] = cmulc(z[k], osc);
+          }
+          if (transient) {
+            const double rs = uniform_f64(fresh_nco(nco)->r_star_sq);
+            transient = fabs(osc_r * osc_r - rs) > 1e-13;
+          }
+          if (DEBUG && a.dbg_nco) {
+            float *dn = a.dbg_nco + ((size_t)ch * a.nframes + f) * (2 * L);
+  #pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              dn[n0 + k] = z[k].x;
+              dn[L + n0 + k] = z[k].y;
+            }
+          }
+          // -- stage into LDS, then decimate by 4 (28 taps): outputs m = 2*lane, 2*lane+1
+          wave_sync();
+          float *xw = lds + kX + 20 * lane;  // lane stride: 8 complex + 1 pad slot = 20 floats
+  #pragma unroll
+          for (int i = 0; i < 4; ++i)  // logical 28 + 8 lane + 2 i  ->  xpad() - 10 lane is a constant
+            *reinterpret_cast<float4 *>(xw + 2 * (xpad(28 + 2 * i))) =
+                make_float4(z[2 * i].x, z[2 * i].y, z[2 * i + 1].x, z[2 * i + 1].y);
+          wave_sync();
+          cf o1[2];
+          // arm_fir_decimate_f32: y[m] = sum_i c[i] * state[4m + i]; state[i] = buf[i + 1]
+          {
+            auto pidx = [](int o) { return xpad(o); };  // window-relative, identical for every lane
+            if (!T41RX_CUT(4)) {
+              fir_pair<kDec1Taps, 1, 5, 18, 6>(xw, pidx, (CFloatPtr)cf0->dec1, o1[0], o1[1]);
+            } else {
+              o1[0] = *reinterpret_cast<cf *>(xw);
+              o1[1] = *reinterpret_cast<cf *>(xw + 8);
+            }
+          }
+          // -- roll the /4 history (logical 512..539 -> 0..27) and append the /4 outputs
+          {
+            float4 hh = make_float4(0, 0, 0, 0);
+            if (lane < 14) hh = lds4(lds + kX + 2 * xpad(512 + 2 * lane));
+            wave_sync();
+            if (lane < 14) *reinterpret_cast<float4 *>(lds + kX + 2 * xpad(2 * lane)) = hh;
+            *reinterpret_cast<float4 *>(lds + kY1 + 2 * (48 + 128 * h + 2 * lane)) =
+                make_float4(o1[0].x, o1[0].y, o1[1].x, o1[1].y);
+          }
+        }  // h
+        // ---- decimate by 2 (46 taps) over the 256 new /4 samples: m = 2*lane, 2*lane+1
+        wave_sync();
+        // y[m] = sum_i c[i] * state[2m + i]; state[i] = buf[i + 3]
         {
-          float x1 = xm1, x2 = xm2;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const float u = b0 * aud[k] + b1 * x1 + b2 * x2;
-            const float yy = u + a1 * s1 + a2 * s2;
-            x2 = x1;
-            x1 = aud[k];
-            s2 = s1;
-            s1 = yy;
-            y[k] = yy;
+          auto lin = [](int o) { return o; };
+          if (!T41RX_CUT(3)) {
+            fir_pair<kDec2Taps, 3, 5, 26, 6>(lds + kY1 + 8 * lane, lin, (CFloatPtr)cf0->dec2, y2[rd][0], y2[rd][1]);
+          } else {
+            y2[rd][0] = *reinterpret_cast<cf *>(lds + kY1 + 8 * lane);
+            y2[rd][1] = *reinterpret_cast<cf *>(lds + kY1 + 8 * lane + 2);
           }
         }
-        // state transition over one lane (4 samples): s_out = P s_in + (s1, s2), P = M^4,
-        // M = [[a1, a2], [1, 0]]; scan with 2x2 matrix powers
-        struct M2 { float a, b, c, d; };
-        auto mm = [](M2 x, M2 y) { return M2{x.a * y.a + x.b * y.c, x.a * y.b + x.b * y.d, x.c * y.a + x.d * y.c, x.c * y.b + x.d * y.d}; };
-        const M2 M{a1, a2, 1.0f, 0.0f};
-        const M2 Mq = mm(M, M);
-        const M2 P1 = mm(Mq, Mq), P2 = mm(P1, P1), P4 = mm(P2, P2), P8 = mm(P4, P4);
-        M2 Q15 = P1, Q31 = P1;
-        for (int i = 0; i < (lane & 15); ++i) Q15 = mm(Q15, P1);
-        for (int i = 0; i < (lane & 31); ++i) Q31 = mm(Q31, P1);
-        auto step = [&](M2 P, float o1, float o2) {
-          s1 = s1 + P.a * o1 + P.b * o2;
-          s2 = s2 + P.c * o1 + P.d * o2;
-        };
-        {
-          float o1 = dpp_f<kDppRowShr1, 0xf, true>(0.0f, s1), o2 = dpp_f<kDppRowShr1, 0xf, true>(0.0f, s2);
-          step(P1, o1, o2);
-          o1 = dpp_f<kDppRowShr2, 0xf, true>(0.0f, s1), o2 = dpp_f<kDppRowShr2, 0xf, true>(0.0f, s2);
-          step(P2, o1, o2);
-          o1 = dpp_f<kDppRowShr4, 0xf, true>(0.0f, s1), o2 = dpp_f<kDppRowShr4, 0xf, true>(0.0f, s2);
-          step(P4, o1, o2);
-          o1 = dpp_f<kDppRowShr8, 0xf, true>(0.0f, s1), o2 = dpp_f<kDppRowShr8, 0xf, true>(0.0f, s2);
-          step(P8, o1, o2);
-          o1 = dpp_f<kDppRowBcast15, 0xa, false>(0.0f, s1), o2 = dpp_f<kDppRowBcast15, 0xa, false>(0.0f, s2);
-          step(Q15, o1, o2);
-          o1 = dpp_f<kDppRowBcast31, 0xc, false>(0.0f, s1), o2 = dpp_f<kDppRowBcast31, 0xc, false>(0.0f, s2);
-          step(Q31, o1, o2);
+        {  // roll the /2 history: logical 256..303 -> 0..47
+          float4 hh = make_float4(0, 0, 0, 0);
+          if (lane < 24) hh = lds4(lds + kY1 + 2 * (256 + 2 * lane));
+          wave_sync();
+          if (lane < 24) *reinterpret_cast<float4 *>(lds + kY1 + 4 * lane) = hh;
         }
-        // carry entering my chunk = inclusive state of lane-1; fix up y_k += (M^(k+1) e)[0]
-        const float e1 = lane_up1(s1), e2 = lane_up1(s2);
-        M2 Mk = M;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          y[k] += Mk.a * e1 + Mk.b * e2;
-          Mk = mm(M, Mk);
-        }
-        if (lane == 63) *reinterpret_cast<float4 *>(ms + kMiscLp1) = make_float4(aud[3], aud[2], y[3], y[2]);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) aud[k] = y[k];
-      }
-    }
-    if (DEBUG && a.dbg_demod) {
-      float *dm = a.dbg_demod + ((size_t)ch * a.nframes + f) * D;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) dm[(MODE == kModeAm) ? 4 * lane + j : lane + 64 * j] = aud[j];
-    }
+      }  // rd
+      phase0 += (uint64_t)L * dphi;
+      if (PART == 0 || (f & 7) == 7) dc_carry = uniform_f32(dc2.y);  // the shared biquad ends the frame on Q
 
+      // ---- delay lines back to HBM (the LDS copies are about to be reused as scratch); issue
+      // the small back-end history loads now so the FFT hides their latency
+      wave_sync();
+      if (lane < 14) *reinterpret_cast<float4 *>(st + kStDec1 + 4 * lane) = lds4(lds + kX + 2 * xpad(2 * lane));
+      if (lane < 24) *reinterpret_cast<float4 *>(st + kStDec2 + 4 * lane) = lds4(lds + kY1 + 4 * lane);
+      if (lane < 6) hist1 = *reinterpret_cast<const float4 *>(st + kStInt1 + 4 * lane);
+      if (lane < 8) hist2 = st[kStInt2 + lane];
+      wave_sync();
+
+      // ---- level adjust (Process.cpp:481-492)
+      const float level = fresh_coef(cf0)->sc[kScLevel];
+  #pragma unroll
+      for (int rd = 0; rd < 2; ++rd)
+  #pragma unroll
+        for (int e = 0; e < 2; ++e) y2[rd][e] *= splat(level);
+      if (DEBUG && a.dbg_dec) {
+        float *dd = a.dbg_dec + ((size_t)ch * a.nframes + f) * N;
+  #pragma unroll
+        for (int rd = 0; rd < 2; ++rd)
+  #pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            dd[128 * rd + 2 * lane + e] = y2[rd][e].x;
+            dd[D + 128 * rd + 2 * lane + e] = y2[rd][e].y;
+          }
+      }
+
+      if (PART == 1) {  // front half of the 4096 pipeline: hand the 256 new /8 samples to the fast-conv kernel
+        float *mid = a.mid + ((size_t)ch * a.nframes + f) * (2 * D);
+  #pragma unroll
+        for (int rd = 0; rd < 2; ++rd)
+          *reinterpret_cast<float4 *>(mid + 2 * (128 * rd + 2 * lane)) =
+              make_float4(y2[rd][0].x, y2[rd][0].y, y2[rd][1].x, y2[rd][1].y);
+        continue;
+      }
+      // ---- NFM (Process.cpp:716-727): quadri-correlator discriminator on the 256 new complex
+      // samples, hard limiter, then the demodulated REAL audio goes through the same overlap-save
+      // filter with zero imaginary part (Process.cpp:765-816)
+      if (MODE == kModeNfm) {
+        // fmdemod_quadri_K (Demod.h:7) is a double: K * (float expr) / (float expr) in double
+        constexpr double K = 0.340447550238101026565118445432744920253753662109375;
+        const cf *ms = reinterpret_cast<const cf *>(st + kStMisc + kMiscNfmI);
+        const cf last = ms[0];  // nfmdemod()'s "last sample", see the quirk note below
+        float au[2][2];
+  #pragma unroll
+        for (int rd = 0; rd < 2; ++rd) {
+          // previous complex sample of m = 128 rd + 2 lane: lane-1's odd sample; lane 0 wraps to the
+          // previous round's last sample
+          cf prev0 = cf{lane_up1(y2[rd][1].x), lane_up1(y2[rd][1].y)};
+          if (rd == 1 && lane == 0)
+            prev0 = cf{__int_as_float(__builtin_amdgcn_readlane(__float_as_int(y2[0][1].x), 63)),
+                       __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y2[0][1].y), 63))};
+          const cf cur0 = y2[rd][0], cur1 = y2[rd][1];
+          // Demod.cpp:229-231: (qnow * ilast - inow * qlast) / (inow^2 + qnow^2)
+          float num0 = cur0.y * prev0.x - cur0.x * prev0.y;
+          const float den0 = cur0.x * cur0.x + cur0.y * cur0.y;
+          const float num1 = cur1.y * cur0.x - cur1.x * cur0.y;
+          const float den1 = cur1.x * cur1.x + cur1.y * cur1.y;
+          if (rd == 0 && lane == 0)  // Demod.cpp:224: first sample of the frame uses the difference form
+            num0 = cur0.x * (cur0.y - last.y) - cur0.y * (cur0.x - last.x);
+          float a0 = (float)(K * (double)num0 / (double)den0);
+          float a1 = (float)(K * (double)num1 / (double)den1);
+          // Process.cpp:719-727: limiter, skips sample 0 of the frame
+          if (!(rd == 0 && lane == 0)) {
+            a0 = (1.0f < a0) ? 1.0f : a0;
+            a0 = (-1.0f > a0) ? -1.0f : a0;
+          }
+          a1 = (1.0f < a1) ? 1.0f : a1;
+          a1 = (-1.0f > a1) ? -1.0f : a1;
+          au[rd][0] = a0;
+          au[rd][1] = a1;
+        }
+        // Demod.cpp:232-233 keeps floats [input_size-2], [input_size-1] of the interleaved buffer
+        // as "last sample": that is complex sample 127 (m = 127: round 0, lane 63, odd), not 255
+        if (lane == 63) *reinterpret_cast<cf *>(st + kStMisc + kMiscNfmI) = y2[0][1];
+  #pragma unroll
+        for (int rd = 0; rd < 2; ++rd)
+  #pragma unroll
+          for (int e = 0; e < 2; ++e) y2[rd][e] = cf{au[rd][e], 0.0f};
+      }
+
+      // ---- overlap-save assemble (Process.cpp:498-522): v[0..3] = previous block, v[4..7] = new
+      {
+        cf *tb = reinterpret_cast<cf *>(lds);
+  #pragma unroll
+        for (int rd = 0; rd < 2; ++rd)
+          *reinterpret_cast<float4 *>(lds + 2 * (128 * rd + 2 * lane)) =
+              make_float4(y2[rd][0].x, y2[rd][0].y, y2[rd][1].x, y2[rd][1].y);
+        wave_sync();
+  #pragma unroll
+        for (int j = 0; j < 4; ++j) v[4 + j] = tb[lane + 64 * j];
+        cf *ov = reinterpret_cast<cf *>(st + kStOverlap);
+  #pragma unroll
+        for (int j = 0; j < 4; ++j) ov[64 * j + lane] = v[4 + j];
+      }
+
+      // ---- FFT, x mask, inverse FFT (Process.cpp:535-595).  The mask table is pre-scaled by 1/N.
+      {
+        cf tw1[7], tw2[7];
+  #pragma unroll
+        for (int q = 0; q < 7; ++q) {
+          tw1[q] = ltab[kLdsTabTw1 + 64 * q + lane];
+          tw2[q] = ltab[kLdsTabTw2 + 8 * q + (lane & 7)];
+        }
+        if (!T41RX_CUT(2)) {
+          fft512<false>(v, tw1, tw2, lds, lane);
+  #pragma unroll
+          for (int r = 0; r < 8; ++r) v[r] = cmul(v[r], ltab[kLdsTabMask + 64 * r + lane]);
+          fft512<true>(v, tw1, tw2, lds, lane);
+        }
+      }
+
+      // ---- AGC off: fixed gain on the valid half (DSP_Fn.cpp:494-502); SSB/NFM: audio = Re
+      const float fixed_gain = fresh_coef(cf0)->sc[kScFixedGain];
+      if (MODE != kModeAm) {
+  #pragma unroll
+        for (int j = 0; j < 4; ++j) aud[j] = fixed_gain * v[4 + j].x;
+      } else {
+        // ---- AM (Process.cpp:697-707): AlphaBetaMag envelope (Utility.cpp:269-285), DC removal
+        // w = m + 0.99 w_old, y = w - w_old, then biquad_lowpass1 (DF1).  Both recurrences run as
+        // wave scans over lane-contiguous chunks of 4 samples.
+  #pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const cf g = v[4 + j] * splat(fixed_gain);
+          const float ai = fabsf(g.x), aq = fabsf(g.y);
+          const float hi = fmaxf(ai, aq), lo = fminf(ai, aq);
+          aud[j] = 0.960433870103f * hi + 0.397824734759f * lo;
+        }
+        wave_sync();
+  #pragma unroll
+        for (int j = 0; j < 4; ++j) lds[24 + lane + 64 * j] = aud[j];
+        wave_sync();
+        const float4 m4 = lds4(lds + 24 + 4 * lane);
+        const float m[4] = {m4.x, m4.y, m4.z, m4.w};
+        float *ms = st + kStMisc;
+        // -- DC block.  The reference accumulates w ~ 100x the signal in f32; here the scan runs in
+        // f64 (no accumulation noise of its own), state kept as the reference's float wold
+        const double ca = (double)0.99f;
+        double wl[4];
+        {
+          double wprev = (lane == 0) ? (double)ms[kMiscWold] : 0.0;
+  #pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            wprev = (double)m[k] + ca * wprev;
+            wl[k] = wprev;
+          }
+        }
+        double B = wl[3];
+        {
+          const double a4 = ca * ca * ca * ca, a8 = a4 * a4, a16 = a8 * a8, a32 = a16 * a16;
+          double p15 = a4, p31 = a4;  // ca^(4 ((lane&15)+1)), ca^(4 ((lane&31)+1))
+          for (int i = 0; i < (lane & 15); ++i) p15 *= a4;
+          for (int i = 0; i < (lane & 31); ++i) p31 *= a4;
+          B = fma(a4, dpp_d<kDppRowShr1, 0xf, true>(B), B);
+          B = fma(a8, dpp_d<kDppRowShr2, 0xf, true>(B), B);
+          B = fma(a16, dpp_d<kDppRowShr4, 0xf, true>(B), B);
+          B = fma(a32, dpp_d<kDppRowShr8, 0xf, true>(B), B);
+          B = fma(p15, dpp_d<kDppRowBcast15, 0xa, false>(B), B);
+          B = fma(p31, dpp_d<kDppRowBcast31, 0xc, false>(B), B);
+          const double e = dpp_d<kDppWaveShr1, 0xf, true>(B);  // w just before my first sample (lane 0: already included)
+          double wk_prev = (lane == 0) ? (double)ms[kMiscWold] : e;
+          double apow = ca;
+  #pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const double wt = (lane == 0) ? wl[k] : wl[k] + apow * e;
+            aud[k] = (float)(wt - wk_prev);
+            wk_prev = wt;
+            apow *= ca;
+          }
+          if (lane == 63) ms[kMiscWold] = (float)wk_prev;
+        }
+        // -- biquad_lowpass1, DF1: y = b0 x + b1 x1 + b2 x2 + a1 y1 + a2 y2 (a's pre-negated)
+        {
+          const CoefPtr c = fresh_coef(cf0);
+          const float b0 = c->lp1[0], b1 = c->lp1[1], b2 = c->lp1[2], a1 = c->lp1[3], a2 = c->lp1[4];
+          const float4 sv = *reinterpret_cast<const float4 *>(ms + kMiscLp1);  // x1, x2, y1, y2
+          float xm1 = lane_up1(aud[3]), xm2 = lane_up1(aud[2]);
+          if (lane == 0) {
+            xm1 = sv.x;
+            xm2 = sv.y;
+          }
+          float y[4];
+          float s1 = (lane == 0) ? sv.z : 0.0f, s2 = (lane == 0) ? sv.w : 0.0f;  // y[n-1], y[n-2]
+          {
+            float x1 = xm1, x2 = xm2;
+  #pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float u = b0 * aud[k] + b1 * x1 + b2 * x2;
+              const float yy = u + a1 * s1 + a2 * s2;
+              x2 = x1;
+              x1 = aud[k];
+              s2 = s1;
+              s1 = yy;
+              y[k] = yy;
+            }
+          }
+          // state transition over one lane (4 samples): s_out = P s_in + (s1, s2), P = M^4,
+          // M = [[a1, a2], [1, 0]]; scan with 2x2 matrix powers
+          struct M2 { float a, b, c, d; };
+          auto mm = [](M2 x, M2 y) { return M2{x.a * y.a + x.b * y.c, x.a * y.b + x.b * y.d, x.c * y.a + x.d * y.c, x.c * y.b + x.d * y.d}; };
+          const M2 M{a1, a2, 1.0f, 0.0f};
+          const M2 Mq = mm(M, M);
+          const M2 P1 = mm(Mq, Mq), P2 = mm(P1, P1), P4 = mm(P2, P2), P8 = mm(P4, P4);
+          M2 Q15 = P1, Q31 = P1;
+          for (int i = 0; i < (lane & 15); ++i) Q15 = mm(Q15, P1);
+          for (int i = 0; i < (lane & 31); ++i) Q31 = mm(Q31, P1);
+          auto step = [&](M2 P, float o1, float o2) {
+            s1 = s1 + P.a * o1 + P.b * o2;
+            s2 = s2 + P.c * o1 + P.d * o2;
+          };
+          {
+            float o1 = dpp_f<kDppRowShr1, 0xf, true>(0.0f, s1), o2 = dpp_f<kDppRowShr1, 0xf, true>(0.0f, s2);
+            step(P1, o1, o2);
+            o1 = dpp_f<kDppRowShr2, 0xf, true>(0.0f, s1), o2 = dpp_f<kDppRowShr2, 0xf, true>(0.0f, s2);
+            step(P2, o1, o2);
+            o1 = dpp_f<kDppRowShr4, 0xf, true>(0.0f, s1), o2 = dpp_f<kDppRowShr4, 0xf, true>(0.0f, s2);
+            step(P4, o1, o2);
+            o1 = dpp_f<kDppRowShr8, 0xf, true>(0.0f, s1), o2 = dpp_f<kDppRowShr8, 0xf, true>(0.0f, s2);
+            step(P8, o1, o2);
+            o1 = dpp_f<kDppRowBcast15, 0xa, false>(0.0f, s1), o2 = dpp_f<kDppRowBcast15, 0xa, false>(0.0f, s2);
+            step(Q15, o1, o2);
+            o1 = dpp_f<kDppRowBcast31, 0xc, false>(0.0f, s1), o2 = dpp_f<kDppRowBcast31, 0xc, false>(0.0f, s2);
+            step(Q31, o1, o2);
+          }
+          // carry entering my chunk = inclusive state of lane-1; fix up y_k += (M^(k+1) e)[0]
+          const float e1 = lane_up1(s1), e2 = lane_up1(s2);
+          M2 Mk = M;
+  #pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            y[k] += Mk.a * e1 + Mk.b * e2;
+            Mk = mm(M, Mk);
+          }
+          if (lane == 63) *reinterpret_cast<float4 *>(ms + kMiscLp1) = make_float4(aud[3], aud[2], y[3], y[2]);
+  #pragma unroll
+          for (int k = 0; k < 4; ++k) aud[k] = y[k];
+        }
+      }
+      if (DEBUG && a.dbg_demod) {
+        float *dm = a.dbg_demod + ((size_t)ch * a.nframes + f) * D;
+  #pragma unroll
+        for (int j = 0; j < 4; ++j) dm[(MODE == kModeAm) ? 4 * lane + j : lane + 64 * j] = aud[j];
+      }
+
+    }
     if (T41RX_CUT(1)) {
 #pragma unroll
       for (int u = 0; u < 8; ++u)
@@ -973,10 +1001,103 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
     }
   }  // frames
 
-  if (lane == 0) {
+  if (PART != 2 && lane == 0) {
     ncs->phase = phase0;
     ncs->r = osc_r;
     st[kStMisc + kMiscDc] = dc_carry;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// FFT_LENGTH 4096 (BASELINE config 4, a synthetic generalisation: the firmware is compiled for
+// 512): overlap-save fast convolution of one channel per wave.  4096 = 8 x 512:
+//   pass 1 (DIF radix-8 over p, x[k' + 512 p]): DFT8, twiddle W4096^(k' q)  -> Z[q][k'] in place
+//   pass 2 per q: fft512 over k' -> X[q + 8 m]; x mask; inverse fft512 over m -> W[q][k'] in place
+//   pass 3 (inverse of pass 1): conj twiddle, inverse DFT8 over q -> y[k' + 512 p], natural order
+// The 4096-point working array lives in LDS (32 KiB, every access is lane-contiguous), the
+// 512-point sub-FFTs are the same register/LDS-exchange code as the 512 path.
+// ------------------------------------------------------------------------------------------
+constexpr int kFcArrayFloats = 2 * 4096;
+constexpr int kFcLdsFloats = kFcArrayFloats + 8 * kFftRow * 2;  // + fft512 exchange scratch
+
+__global__ __launch_bounds__(64) void fastconv4096_kernel(const RxArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int N = 4096, D = 2048;
+  const int lane = threadIdx.x;
+  const int ch = blockIdx.x;
+  if (ch >= a.nchan) return;
+  cf *A = reinterpret_cast<cf *>(smem);
+  float *xbuf = smem + kFcArrayFloats;
+  float *st = a.state + (size_t)ch * state_floats(N);
+  const cf *tw4k = reinterpret_cast<const cf *>(a.tab4k) + kTab4kTw;
+  const cf *mask4k = reinterpret_cast<const cf *>(a.tab4k) + kTab4kMask;
+  const cf *tab = reinterpret_cast<const cf *>(a.tab);
+  const float fixed_gain = ((CoefPtr)a.coef)->sc[kScFixedGain];
+
+  cf tw1[7], tw2[7];
+#pragma unroll
+  for (int q = 0; q < 7; ++q) {
+    tw1[q] = tab[kTabTw1 + 64 * q + lane];
+    tw2[q] = tab[kTabTw2 + 64 * q + lane];
+  }
+
+  for (int f = 0; f < a.nframes4k; ++f) {
+    // ---- overlap-save assemble (Process.cpp:498-522): [previous 2048 | new 2048]
+    const float4 *prev = reinterpret_cast<const float4 *>(st + kStOverlap);
+    const float4 *mid = reinterpret_cast<const float4 *>(a.mid + ((size_t)ch * a.nframes4k + f) * (2 * D));
+    float4 *A4 = reinterpret_cast<float4 *>(smem);
+    wave_sync();
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+      const float4 p = prev[64 * i + lane];
+      const float4 n = mid[64 * i + lane];
+      A4[64 * i + lane] = p;
+      A4[1024 + 64 * i + lane] = n;
+      reinterpret_cast<float4 *>(st + kStOverlap)[64 * i + lane] = n;  // next frame's "previous"
+    }
+    wave_sync();
+    // ---- pass 1
+#pragma unroll 1
+    for (int r = 0; r < 8; ++r) {
+      const int k = lane + 64 * r;
+      cf v[8];
+#pragma unroll
+      for (int p = 0; p < 8; ++p) v[p] = A[k + 512 * p];
+      dft8<false>(v);
+#pragma unroll
+      for (int q = 1; q < 8; ++q) v[q] = cmul(v[q], tw4k[512 * (q - 1) + k]);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) A[k + 512 * q] = v[q];
+    }
+    wave_sync();
+    // ---- pass 2: 512-point FFT, mask (pre-scaled by 1/4096), inverse 512-point FFT, per q
+#pragma unroll 1
+    for (int q = 0; q < 8; ++q) {
+      cf v[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] = A[512 * q + lane + 64 * r];
+      fft512<false>(v, tw1, tw2, xbuf, lane);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] = cmul(v[r], mask4k[512 * q + lane + 64 * r]);
+      fft512<true>(v, tw1, tw2, xbuf, lane);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) A[512 * q + lane + 64 * r] = v[r];
+    }
+    wave_sync();
+    // ---- pass 3; AGC off: fixed gain (DSP_Fn.cpp:494-502); SSB: audio = Re of the valid half
+    float *au = a.aud24 + ((size_t)ch * a.nframes4k + f) * D;
+#pragma unroll 1
+    for (int r = 0; r < 8; ++r) {
+      const int k = lane + 64 * r;
+      cf v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = A[k + 512 * q];
+#pragma unroll
+      for (int q = 1; q < 8; ++q) v[q] = cmulc(v[q], tw4k[512 * (q - 1) + k]);
+      dft8<true>(v);
+#pragma unroll
+      for (int p = 4; p < 8; ++p) au[k + 512 * (p - 4)] = fixed_gain * v[p].x;
+    }
   }
 }
 
@@ -991,14 +1112,31 @@ static hipError_t launch512(const RxArgs &a, hipStream_t s, bool debug) {
   const size_t lds = 40960;
   static_assert((kLdsTabFloats + 4 * kLdsFloatsPerWave) * sizeof(float) <= 40960, "LDS slice too large");
   if (debug)
-    hipLaunchKernelGGL((rx512_kernel<MODE, true>), dim3(grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((rx512_kernel<MODE, true, 0>), dim3(grid), dim3(256), lds, s, a);
   else
-    hipLaunchKernelGGL((rx512_kernel<MODE, false>), dim3(grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((rx512_kernel<MODE, false, 0>), dim3(grid), dim3(256), lds, s, a);
+  return hipGetLastError();
+}
+
+// FFT_LENGTH 4096: front half (8 segments per frame) -> 4096-point fast convolution -> back half
+static hipError_t launch4096(const RxArgs &a, hipStream_t s) {
+  const int grid = (a.nchan + 3) / 4;
+  hipLaunchKernelGGL((rx512_kernel<kModeSsb, false, 1>), dim3(grid), dim3(256), 40960, s, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(fastconv4096_kernel, dim3(a.nchan), dim3(64), kFcLdsFloats * sizeof(float), s, a);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((rx512_kernel<kModeSsb, false, 2>), dim3(grid), dim3(256), 40960, s, a);
   return hipGetLastError();
 }
 
 hipError_t launch_rx(const RxArgs &a, int fft_length, int mode, hipStream_t s) {
   const bool debug = a.dbg_nco || a.dbg_dec || a.dbg_demod;
+  if (fft_length == 4096) {
+    if (mode != T41RX_DEMOD_USB && mode != T41RX_DEMOD_LSB) return hipErrorInvalidValue;
+    return launch4096(a, s);
+  }
   if (fft_length != 512) return hipErrorInvalidValue;
   switch (mode) {
     case T41RX_DEMOD_USB:

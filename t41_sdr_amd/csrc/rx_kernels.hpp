@@ -33,7 +33,19 @@ struct RxArgs {
   float *dbg_nco;
   float *dbg_dec;
   float *dbg_demod;
+  // FFT_LENGTH 4096 pipeline scratch (device, owned by the context)
+  float *mid;              // [nchan][nseg * 256] complex: /8-decimated, level-adjusted I/Q
+  float *aud24;            // [nchan][nseg * 256] real: filtered audio @24 kS/s
+  const float2 *tab4k;     // tw4096[7][512] | mask4096[8][512] (see kTab4k*)
+  int nframes4k;           // number of 4096-frames (= nframes / 8 for the part kernels)
 };
+
+// constant table of the 4096-point fast convolution (float2 units):
+//   tw4k  [7][512] : W4096^(k' q), q = 1..7, k' < 512 (forward sign)
+//   mask4k[8][512] : FIR_filter_mask[q + 8 m] / 4096 at [q][m]
+constexpr int kTab4kTw = 0;
+constexpr int kTab4kMask = 7 * 512;
+constexpr int kTab4kEntries = 7 * 512 + 8 * 512;
 
 hipError_t launch_rx(const RxArgs &a, int fft_length, int mode, hipStream_t s);
 

@@ -34,6 +34,7 @@ def T(built):
 
 def gpu_run(T, kw, nco, I, Q, split=None):
     import torch
+    kw = dict(kw)
     rx = T.RxChain(I.shape[0], T.default_params(**kw), NCOFreq=nco)
     dI, dQ = torch.from_numpy(I).cuda(), torch.from_numpy(Q).cuda()
     if split is None:
@@ -98,6 +99,24 @@ def test_parity_nfm(T):
     assert err.max() <= TOL, (err.max(), np.unravel_index(err.argmax(), err.shape))
     # frame-by-frame == one call (the discriminator's odd "last sample" state included)
     split, _ = gpu_run(T, kw, nco, I, Q, split=[k * L for k in range(nfr + 1)])
+    assert np.array_equal(got, split)
+
+
+def test_parity_fft4096(T):
+    """BASELINE config 4 (synthetic generalisation): FFT_LENGTH 4096, 16384-sample
+    frames, 2049-tap narrow USB filter (400..600 Hz), three-kernel pipeline"""
+    Lf = 16384
+    nch, nfr = 12, 4
+    nco = siggen.nco_grid(nch, seed=23)
+    kw = dict(fft_length=4096, mode=0, FLoCut=400, FHiCut=600)
+    I, Q = siggen.make_iq(nch, nfr * Lf, nco, mode=0, seed=41, audio_hz=(450.0, 550.0))
+    got, _ = gpu_run(T, kw, nco, I, Q)
+    ref = oracle_run(kw, nco, I, Q)
+    err = siggen.block_rel_err(got, ref, Lf)
+    # frame 0 is almost pure filter start-up (2049-tap filter): compared absolutely by block_rel_err's rule
+    assert err[:, 1:].max() <= TOL, (err.max(), np.unravel_index(err.argmax(), err.shape))
+    assert np.abs(got[:, :Lf] - ref[:, :Lf]).max() <= 1e-5 * max(np.abs(ref).max(), 1e-30)
+    split, _ = gpu_run(T, kw, nco, I, Q, split=[0, Lf, 3 * Lf, nfr * Lf])
     assert np.array_equal(got, split)
 
 
@@ -243,7 +262,7 @@ def test_argument_errors(T):
     with pytest.raises(T.T41RxError) as e:
         rx.SetNCOFreq(np.full(4, 200000))
     assert e.value.status == _lib.ERR_ARG
-    for unsupported in (dict(AGCMode=1), dict(fft_length=4096, FLoCut=400, FHiCut=600)):
+    for unsupported in (dict(AGCMode=1), dict(fft_length=1024), dict(fft_length=4096, mode=3)):
         with pytest.raises(T.T41RxError) as e:
             T.RxChain(4, T.default_params(**unsupported))
         assert e.value.status == _lib.ERR_UNSUPPORTED

@@ -407,20 +407,25 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ch = blockIdx.x * 4 + wv;
 
-  // ---- stage mask + twiddles in LDS once per workgroup (the only workgroup barrier)
-  {
+  // mask + twiddles are staged in LDS once per workgroup (the only workgroup barrier).  The
+  // staging runs AFTER the first frame's global loads have been issued, so its latency and the
+  // barrier overlap with the HBM latency of the input instead of preceding it.
+  auto stage_tables = [&]() {
     const float4 *src = reinterpret_cast<const float4 *>(a.tab);
     float4 *dst = reinterpret_cast<float4 *>(smem);
 #pragma unroll
     for (int i = threadIdx.x; i < (512 + 448) / 2; i += 256) dst[i] = src[i];  // mask, tw1
     if (threadIdx.x < 56)  // tw2[q][l1] = table entry [q][lane = l1]
       reinterpret_cast<float2 *>(smem)[kLdsTabTw2 + threadIdx.x] = a.tab[kTabTw2 + 64 * (threadIdx.x >> 3) + (threadIdx.x & 7)];
-  }
+    __syncthreads();
+  };
   // per-lane constants of the DC high-pass scan
   const float2 hp8 = a.tab[kTabHp8 + lane];
   const float2 hp4 = a.tab[kTabHp4 + lane];
-  __syncthreads();
-  if (ch >= a.nchan) return;  // whole wave leaves; no further workgroup barriers
+  if (ch >= a.nchan) {  // ragged last workgroup: help with the staging, meet the barrier, leave
+    stage_tables();
+    return;
+  }
 
   const cf *ltab = reinterpret_cast<const cf *>(smem);
   float *lds = smem + kLdsTabFloats + wv * kLdsFloatsPerWave;
@@ -462,6 +467,7 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
       for (int j = 0; j < 4; ++j) aud[j] = au[lane + 64 * j];
       if (lane < 6) hist1 = *reinterpret_cast<const float4 *>(st + kStInt1 + 4 * lane);
       if (lane < 8) hist2 = st[kStInt2 + lane];
+      if (f == 0) stage_tables();
     } else {
       // ---- first loads of the frame
       float4 nI0 = *reinterpret_cast<const float4 *>(gI + 8 * lane);
@@ -476,6 +482,8 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
         *reinterpret_cast<float4 *>(lds + kX + 2 * xpad(2 * lane)) = *reinterpret_cast<const float4 *>(st + kStDec1 + 4 * lane);
       if (lane < 24)
         *reinterpret_cast<float4 *>(lds + kY1 + 4 * lane) = *reinterpret_cast<const float4 *>(st + kStDec2 + 4 * lane);
+
+      if (f == 0) stage_tables();
 
       // gains (Process.cpp:117-134, 165-166).  g_band and -IQAmp are folded into one factor on I
       // (exact whenever either is +-1, which is the firmware default; one rounding otherwise)

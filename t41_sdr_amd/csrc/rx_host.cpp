@@ -417,6 +417,12 @@ int t41rx_process_device(t41rx_ctx *ctx, const float *dI, const float *dQ, float
   a.mid = ctx->d_mid;
   a.aud24 = ctx->d_aud24;
   a.tab4k = ctx->d_tab4k;
+  {
+    const float *sc = blob_view(ctx->blob.data()).scalars;
+    const bool iq_on = sc[kScIqCorrOn] != 0.0f;
+    const float gi = iq_on ? sc[kScBandGain] * sc[kScNegIqAmp] : sc[kScBandGain];
+    a.plain = ((gi == 1.0f || (iq_on && gi == -1.0f)) && sc[kScBandGain] == 1.0f && (!iq_on || sc[kScIqPhase] == 0.0f)) ? 1 : 0;
+  }
   a.dbg_nco = ctx->dbg_nco;
   a.dbg_dec = ctx->dbg_dec;
   a.dbg_demod = ctx->dbg_demod;

@@ -62,6 +62,23 @@ __device__ __forceinline__ void wave_sync() {
 #endif
 #define T41RX_CUT(n) (T41RX_ABLATE >= (n) && T41RX_ABLATE <= 8)
 
+// Diagnostic build only (-DT41RX_STAMP): s_memtime stamps at phase boundaries; lane p of each wave
+// accumulates the cycles of phase p and writes them behind the demod debug tap at the end.
+// The stamps drain lgkmcnt, so read the SHARES, not the total.
+#ifdef T41RX_STAMP
+#define STAMP(p)                                                                     \
+  do {                                                                               \
+    unsigned long long t_;                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                               \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+    __builtin_amdgcn_sched_barrier(0);                                               \
+    if (lane == (p)) stamp_acc += t_ - stamp_last;                                   \
+    stamp_last = t_;                                                                 \
+  } while (0)
+#else
+#define STAMP(p) do {} while (0)
+#endif
+
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef f2 cf;  // .x = re / I, .y = im / Q, one even-aligned VGPR pair
 
@@ -398,7 +415,12 @@ constexpr int kModeSsb = 0, kModeAm = 1, kModeNfm = 2;  // kernel template MODE
 // FFT_LENGTH 4096 pipeline (front: loads .. /8 decimation + level adjust -> `mid`; back:
 // `aud24` -> interpolators -> store): a 16384-sample frame is 8 consecutive 2048-sample segments
 // for them, the 4096-point fast convolution in between is fastconv4096_kernel.
-template <int MODE, bool DEBUG, int PART>
+// PLAIN: band gain 1, |IQ amplitude correction| 1 and IQ phase correction 0 (the firmware defaults:
+// bands[].RFgain 1, gwv.cpp:71-72).  Those stages then vanish from the instruction stream: the one
+// thing left, the reference's I <- -I (Process.cpp:166), is folded into the sign of the RF-gain
+// multiply of I, which is exact because the DC high-pass in between is linear and negation is exact
+// (the I chain's carry is negated with it).
+template <int MODE, bool DEBUG, int PART, bool PLAIN>
 __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int L = 2048, D = 256, N = 512;
@@ -437,19 +459,25 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
   const NcoPtr nco = (NcoPtr)(a.nco + ch);
   const float2 *__restrict__ tab = a.tab;
 
-  // per-channel NCO constants and state (wave-uniform)
-  const uint64_t dphi = uniform_u64(nco->phase_inc);
+  // per-channel NCO constants and state (wave-uniform).  Only the LOADS are issued here; the
+  // values are made uniform (which waits for them) after the first frame's input loads are in
+  // flight, so the kernel's cold start is one memory round trip, not a chain of them.
   NcoState *ncs = reinterpret_cast<NcoState *>(st + kStNco);
-  uint64_t phase0 = uniform_u64(ncs->phase);
-  double osc_r = uniform_f64(ncs->r);
-  float dc_carry = uniform_f32(st[kStMisc + kMiscDc]);
-  bool transient;
-  {
-    const double rs = uniform_f64(nco->r_star_sq);
-    transient = fabs(osc_r * osc_r - rs) > 1e-13;
-  }
+  const uint64_t raw_dphi = nco->phase_inc;
+  const double raw_rs = nco->r_star_sq;
+  const uint64_t raw_phase = ncs->phase;
+  const double raw_r = ncs->r;
+  const float raw_dc = st[kStMisc + kMiscDc];
+  uint64_t dphi = 0, phase0 = 0;
+  double osc_r = 1.0;
+  float dc_carry = 0.0f;
+  bool transient = false;
 
   f2 dc2 = splat(0.0f);  // DC high-pass carries, see below
+#ifdef T41RX_STAMP
+  unsigned long long stamp_acc = 0, stamp_last;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
+#endif
   for (int f = 0; f < a.nframes; ++f) {
     const size_t fbase = ((size_t)(T41RX_ABLATE == 9 ? (ch & 15) : ch) * a.nframes + f) * L;
     const float *__restrict__ gI = a.I + fbase;
@@ -469,35 +497,52 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
       if (lane < 8) hist2 = st[kStInt2 + lane];
       if (f == 0) stage_tables();
     } else {
-      // ---- first loads of the frame
-      float4 nI0 = *reinterpret_cast<const float4 *>(gI + 8 * lane);
-      float4 nI1 = *reinterpret_cast<const float4 *>(gI + 8 * lane + 4);
-      float4 nQ0 = *reinterpret_cast<const float4 *>(gQ + 8 * lane);
-      float4 nQ1 = *reinterpret_cast<const float4 *>(gQ + 8 * lane + 4);
+      // ---- first loads of the frame, issued in the order they are needed (vmcnt retires in
+      // order): sub-block 0, the I tail for Q's DC-block start state, the delay lines, then
+      // sub-block 1.  Input prefetch runs TWO sub-blocks ahead (two register sets, even / odd).
+      float4 pI0[2], pI1[2], pQ0[2], pQ1[2];
+      pI0[0] = *reinterpret_cast<const float4 *>(gI + 8 * lane);
+      pI1[0] = *reinterpret_cast<const float4 *>(gI + 8 * lane + 4);
+      pQ0[0] = *reinterpret_cast<const float4 *>(gQ + 8 * lane);
+      pQ1[0] = *reinterpret_cast<const float4 *>(gQ + 8 * lane + 4);
       const float4 tailI = *reinterpret_cast<const float4 *>(gI + (L - 256) + 4 * lane);
-
-      // ---- delay lines HBM -> LDS (every frame is self-contained: load state, run, store state)
-      wave_sync();
-      if (lane < 14)
-        *reinterpret_cast<float4 *>(lds + kX + 2 * xpad(2 * lane)) = *reinterpret_cast<const float4 *>(st + kStDec1 + 4 * lane);
-      if (lane < 24)
-        *reinterpret_cast<float4 *>(lds + kY1 + 4 * lane) = *reinterpret_cast<const float4 *>(st + kStDec2 + 4 * lane);
-
-      if (f == 0) stage_tables();
-
+      float4 h1 = make_float4(0, 0, 0, 0), h2 = make_float4(0, 0, 0, 0);
+      if (lane < 14) h1 = *reinterpret_cast<const float4 *>(st + kStDec1 + 4 * lane);
+      if (lane < 24) h2 = *reinterpret_cast<const float4 *>(st + kStDec2 + 4 * lane);
       // gains (Process.cpp:117-134, 165-166).  g_band and -IQAmp are folded into one factor on I
       // (exact whenever either is +-1, which is the firmware default; one rounding otherwise)
-      float g_rf, iq_phase;
-      f2 g_iq;
-      bool unit_gain;
+      float g_rf, g_rf_i, iq_phase_neg = 0.0f, iq_phase_pos = 0.0f;
+      f2 g_iq = splat(1.0f);
       {
         const CoefPtr c = fresh_coef(cf0);
         g_rf = c->sc[kScRfGain];
-        const float gb = c->sc[kScBandGain];
-        const bool iq_on = c->sc[kScIqCorrOn] != 0.0f;
-        g_iq = f2{iq_on ? gb * c->sc[kScNegIqAmp] : gb, gb};
-        unit_gain = (g_iq.x == 1.0f) && (g_iq.y == 1.0f);
-        iq_phase = iq_on ? c->sc[kScIqPhase] : 0.0f;
+        // PLAIN: sign of the I path (-1 when the IQ amplitude correction applies, Process.cpp:165-173)
+        g_rf_i = (PLAIN && c->sc[kScIqCorrOn] != 0.0f) ? -g_rf : g_rf;
+        if (!PLAIN) {
+          const float gb = c->sc[kScBandGain];
+          const bool iq_on = c->sc[kScIqCorrOn] != 0.0f;
+          g_iq = f2{iq_on ? gb * c->sc[kScNegIqAmp] : gb, gb};
+          const float ph = iq_on ? c->sc[kScIqPhase] : 0.0f;
+          iq_phase_neg = ph < 0.0f ? ph : 0.0f;
+          iq_phase_pos = ph > 0.0f ? ph : 0.0f;
+        }
+      }
+      if (f == 0) stage_tables();
+      pI0[1] = *reinterpret_cast<const float4 *>(gI + 512 + 8 * lane);
+      pI1[1] = *reinterpret_cast<const float4 *>(gI + 512 + 8 * lane + 4);
+      pQ0[1] = *reinterpret_cast<const float4 *>(gQ + 512 + 8 * lane);
+      pQ1[1] = *reinterpret_cast<const float4 *>(gQ + 512 + 8 * lane + 4);
+
+      // ---- delay lines -> LDS (every frame is self-contained: load state, run, store state)
+      wave_sync();
+      if (lane < 14) *reinterpret_cast<float4 *>(lds + kX + 2 * xpad(2 * lane)) = h1;
+      if (lane < 24) *reinterpret_cast<float4 *>(lds + kY1 + 4 * lane) = h2;
+      if (f == 0) {
+        dphi = uniform_u64(raw_dphi);
+        phase0 = uniform_u64(raw_phase);
+        osc_r = uniform_f64(raw_r);
+        dc_carry = uniform_f32(raw_dc);
+        transient = fabs(osc_r * osc_r - uniform_f64(raw_rs)) > 1e-13;
       }
 
       // ---- Q's DC-block start state = state after ALL of this frame's I (one shared biquad
@@ -510,67 +555,68 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
       if (PART == 0 || (f & 7) == 0) {
         const float4 tailF = (PART == 0) ? tailI : *reinterpret_cast<const float4 *>(gI + (8 * L - 256) + 4 * lane);
         const float x[4] = {tailF.x * g_rf, tailF.y * g_rf, tailF.z * g_rf, tailF.w * g_rf};
-        dc2 = f2{dc_carry, dc_highpass_end_state<4>(x, hp4.x, hp4.y)};
+        dc2 = f2{(g_rf_i != g_rf) ? -dc_carry : dc_carry, dc_highpass_end_state<4>(x, hp4.x, hp4.y)};
       }
 
+      STAMP(15);  // frame prologue: state restore, table staging, Q's DC-block start state
       cf y2[2][2];  // /8 outputs of this frame: m = 128*round + 2*lane + e
       cf v[8];      // FFT registers; v[0..3] = previous block, prefetched below
 
   #pragma unroll
       for (int rd = 0; rd < 2; ++rd) {
-  #pragma unroll 1
+  #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int s = 2 * rd + h;
           // -- RF gain (Process.cpp:117-119); the multiply also interleaves I and Q into pairs
           cf z[8];
-          z[0] = cf{nI0.x * g_rf, nQ0.x * g_rf};
-          z[1] = cf{nI0.y * g_rf, nQ0.y * g_rf};
-          z[2] = cf{nI0.z * g_rf, nQ0.z * g_rf};
-          z[3] = cf{nI0.w * g_rf, nQ0.w * g_rf};
-          z[4] = cf{nI1.x * g_rf, nQ1.x * g_rf};
-          z[5] = cf{nI1.y * g_rf, nQ1.y * g_rf};
-          z[6] = cf{nI1.z * g_rf, nQ1.z * g_rf};
-          z[7] = cf{nI1.w * g_rf, nQ1.w * g_rf};
-          if (s < 3) {  // prefetch the next sub-block
-            const int o = 512 * (s + 1) + (T41RX_CUT(8) ? 4 : 8) * lane;
-            const int o2 = T41RX_CUT(8) ? 256 : 4;
-            nI0 = *reinterpret_cast<const float4 *>(gI + o);
-            nI1 = *reinterpret_cast<const float4 *>(gI + o + o2);
-            nQ0 = *reinterpret_cast<const float4 *>(gQ + o);
-            nQ1 = *reinterpret_cast<const float4 *>(gQ + o + o2);
-          } else {  // last sub-block: prefetch the overlap-save "previous" block instead
+          z[0] = cf{pI0[h].x * g_rf_i, pQ0[h].x * g_rf};
+          z[1] = cf{pI0[h].y * g_rf_i, pQ0[h].y * g_rf};
+          z[2] = cf{pI0[h].z * g_rf_i, pQ0[h].z * g_rf};
+          z[3] = cf{pI0[h].w * g_rf_i, pQ0[h].w * g_rf};
+          z[4] = cf{pI1[h].x * g_rf_i, pQ1[h].x * g_rf};
+          z[5] = cf{pI1[h].y * g_rf_i, pQ1[h].y * g_rf};
+          z[6] = cf{pI1[h].z * g_rf_i, pQ1[h].z * g_rf};
+          z[7] = cf{pI1[h].w * g_rf_i, pQ1[h].w * g_rf};
+          if (s < 2) {  // refill this register set with the sub-block after next
+            const int o = 512 * (s + 2) + 8 * lane;
+            pI0[h] = *reinterpret_cast<const float4 *>(gI + o);
+            pI1[h] = *reinterpret_cast<const float4 *>(gI + o + 4);
+            pQ0[h] = *reinterpret_cast<const float4 *>(gQ + o);
+            pQ1[h] = *reinterpret_cast<const float4 *>(gQ + o + 4);
+          } else if (s == 3) {  // last sub-block: prefetch the overlap-save "previous" block instead
             const cf *ov = reinterpret_cast<const cf *>(st + kStOverlap);
   #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = ov[64 * j + lane];
           }
-          // -- DC high-pass (127-128), band gain (133-134) / IQ amplitude (166)
+          STAMP(s == 0 ? 14 : 0);  // wait for the sub-block's global loads + gain/interleave (14: first sub-block)
+        // -- DC high-pass (127-128), band gain (133-134) / IQ amplitude (166)
           if (!T41RX_CUT(6)) dc_highpass<8>(z, dc2, lane, hp8.x, hp8.y);
-          if (!unit_gain) {
+          if (!PLAIN) {
+            // band gain / IQ amplitude (Process.cpp:133-134, 166) and IQ phase correction
+            // (Utility.cpp:178-187: phi < 0 mixes I into Q, phi > 0 mixes Q into I), branch-free:
+            // at most one of the two phase factors is non-zero
   #pragma unroll
-            for (int k = 0; k < 8; ++k) z[k] *= g_iq;
+            for (int k = 0; k < 8; ++k) {
+              z[k] *= g_iq;
+              z[k].y = fmaf(iq_phase_neg, z[k].x, z[k].y);
+              z[k].x = fmaf(iq_phase_pos, z[k].y, z[k].x);
+            }
           }
-          // -- IQ phase correction (Utility.cpp:178-187)
-          if (iq_phase < 0.0f) {
-  #pragma unroll
-            for (int k = 0; k < 8; ++k) z[k].y = fmaf(iq_phase, z[k].x, z[k].y);
-          } else if (iq_phase > 0.0f) {
-  #pragma unroll
-            for (int k = 0; k < 8; ++k) z[k].x = fmaf(iq_phase, z[k].y, z[k].x);
-          }
-          // -- oscillator for my 8 samples.  Osc_n = V_n * W has phase phase0 + (n+1) dphi.
+          STAMP(1);  // DC high-pass, gains, IQ correction
+        // -- oscillator for my 8 samples.  Osc_n = V_n * W has phase phase0 + (n+1) dphi.
           const int n0 = 512 * s + 8 * lane;
-          float amp[8];
-  #pragma unroll
-          for (int k = 0; k < 8; ++k) amp[k] = 1.0f;
           if (transient) {
             // start-up of the amplitude loop g = 1.95 - |V|^2 (Freq_Shift.cpp:130-134): replay the
-            // scalar recurrence (wave-uniform); each lane keeps its own 8 values.  |Osc_n| / A* =
-            // |V_n| / r*.
+            // scalar recurrence (wave-uniform); each lane scales its own 8 samples by
+            // |Osc_n| / A* = |V_n| / r* (the mix below is linear, so scaling first is equivalent)
             const NcoPtr nt = fresh_nco(nco);
             const double r_star_sq = uniform_f64(nt->r_star_sq);
             const double w_abs = uniform_f64(nt->w_abs);
             const double inv_r = 1.0 / sqrt(r_star_sq);
             double r = osc_r;
+            float amp[8];
+  #pragma unroll
+            for (int k = 0; k < 8; ++k) amp[k] = 1.0f;
             for (int g = 0; g < 64; ++g) {
   #pragma unroll
               for (int k = 0; k < 8; ++k) {
@@ -580,6 +626,9 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
               if (fabs(r * r - r_star_sq) <= 1e-13) break;
             }
             osc_r = r;
+            transient = fabs(osc_r * osc_r - r_star_sq) > 1e-13;
+  #pragma unroll
+            for (int k = 0; k < 8; ++k) z[k] *= splat(amp[k]);
           }
           cf base;
           {
@@ -600,13 +649,8 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
           for (int k = 0; k < 8; ++k) {
             const cf w = cf{ncw->wk[k][0], ncw->wk[k][1]};
             if (T41RX_CUT(5)) continue;
-            cf osc = cmul_s(base, w);
-            if (transient) osc *= splat(amp[k]);
+            const cf osc = cmul_s(base, w);
             z[k] = cmulc(z[k], osc);
-          }
-          if (transient) {
-            const double rs = uniform_f64(fresh_nco(nco)->r_star_sq);
-            transient = fabs(osc_r * osc_r - rs) > 1e-13;
           }
           if (DEBUG && a.dbg_nco) {
             float *dn = a.dbg_nco + ((size_t)ch * a.nframes + f) * (2 * L);
@@ -616,7 +660,8 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
               dn[L + n0 + k] = z[k].y;
             }
           }
-          // -- stage into LDS, then decimate by 4 (28 taps): outputs m = 2*lane, 2*lane+1
+          STAMP(2);  // oscillator + mix
+        // -- stage into LDS, then decimate by 4 (28 taps): outputs m = 2*lane, 2*lane+1
           wave_sync();
           float *xw = lds + kX + 20 * lane;  // lane stride: 8 complex + 1 pad slot = 20 floats
   #pragma unroll
@@ -635,7 +680,8 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
               o1[1] = *reinterpret_cast<cf *>(xw + 8);
             }
           }
-          // -- roll the /4 history (logical 512..539 -> 0..27) and append the /4 outputs
+          STAMP(3);  // LDS staging + /4 decimator
+        // -- roll the /4 history (logical 512..539 -> 0..27) and append the /4 outputs
           {
             float4 hh = make_float4(0, 0, 0, 0);
             if (lane < 14) hh = lds4(lds + kX + 2 * xpad(512 + 2 * lane));
@@ -645,7 +691,8 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
                 make_float4(o1[0].x, o1[0].y, o1[1].x, o1[1].y);
           }
         }  // h
-        // ---- decimate by 2 (46 taps) over the 256 new /4 samples: m = 2*lane, 2*lane+1
+        STAMP(4);  // history roll
+      // ---- decimate by 2 (46 taps) over the 256 new /4 samples: m = 2*lane, 2*lane+1
         wave_sync();
         // y[m] = sum_i c[i] * state[2m + i]; state[i] = buf[i + 3]
         {
@@ -657,7 +704,8 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
             y2[rd][1] = *reinterpret_cast<cf *>(lds + kY1 + 8 * lane + 2);
           }
         }
-        {  // roll the /2 history: logical 256..303 -> 0..47
+        STAMP(5);  // /2 decimator
+      {  // roll the /2 history: logical 256..303 -> 0..47
           float4 hh = make_float4(0, 0, 0, 0);
           if (lane < 24) hh = lds4(lds + kY1 + 2 * (256 + 2 * lane));
           wave_sync();
@@ -667,6 +715,7 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
       phase0 += (uint64_t)L * dphi;
       if (PART == 0 || (f & 7) == 7) dc_carry = uniform_f32(dc2.y);  // the shared biquad ends the frame on Q
 
+      STAMP(4);
       // ---- delay lines back to HBM (the LDS copies are about to be reused as scratch); issue
       // the small back-end history loads now so the FFT hides their latency
       wave_sync();
@@ -762,6 +811,7 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
         for (int j = 0; j < 4; ++j) ov[64 * j + lane] = v[4 + j];
       }
 
+      STAMP(6);  // state save, level, overlap-save assemble
       // ---- FFT, x mask, inverse FFT (Process.cpp:535-595).  The mask table is pre-scaled by 1/N.
       {
         cf tw1[7], tw2[7];
@@ -929,6 +979,7 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
       }
     }
     wave_sync();
+    STAMP(10);  // demod + x2 staging
     f2 u1[4];  // outputs (2n, 2n+1) of input n = 4 lane + u
     {
       float w[28];
@@ -956,6 +1007,7 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
         }
       }
     }
+    STAMP(11);  // x2 interpolator
     // ---- interpolate by 4 (32 taps, phase length 8): inputs n = 8 lane .. 8 lane + 7; the
     // 7-sample history is the neighbouring lane's tail (lane 0: last frame's, from HBM)
     {
@@ -998,6 +1050,7 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
         *reinterpret_cast<float4 *>(lds + 4 * (8 * lane + (u ^ (lane & 7)))) = make_float4(o01.x, o01.y, o23.x, o23.y);
       }
       wave_sync();
+      STAMP(12);  // x4 interpolator + LDS transpose writes
       // ... and every global store instruction then writes 1 KiB of consecutive addresses:
       // float4 index F = 64 i + lane lives in row F >> 3 = 8 i + (lane >> 3), column lane & 7
 #pragma unroll
@@ -1007,7 +1060,13 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
         *reinterpret_cast<float4 *>(gO + 256 * i + 4 * lane) = t;
       }
     }
+    STAMP(13);  // transposed reads + global stores
   }  // frames
+#ifdef T41RX_STAMP
+  // stamps go behind the demod tap's data: dbg_demod must be [nchan*nframes*256 floats | nchan*64 uint64]
+  if (a.dbg_demod)
+    reinterpret_cast<unsigned long long *>(a.dbg_demod + (size_t)a.nchan * a.nframes * D)[(size_t)ch * 64 + lane] = stamp_acc;
+#endif
 
   if (PART != 2 && lane == 0) {
     ncs->phase = phase0;
@@ -1120,22 +1179,24 @@ static hipError_t launch512(const RxArgs &a, hipStream_t s, bool debug) {
   const size_t lds = 40960;
   static_assert((kLdsTabFloats + 4 * kLdsFloatsPerWave) * sizeof(float) <= 40960, "LDS slice too large");
   if (debug)
-    hipLaunchKernelGGL((rx512_kernel<MODE, true, 0>), dim3(grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((rx512_kernel<MODE, true, 0, false>), dim3(grid), dim3(256), lds, s, a);
+  else if (a.plain)
+    hipLaunchKernelGGL((rx512_kernel<MODE, false, 0, true>), dim3(grid), dim3(256), lds, s, a);
   else
-    hipLaunchKernelGGL((rx512_kernel<MODE, false, 0>), dim3(grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((rx512_kernel<MODE, false, 0, false>), dim3(grid), dim3(256), lds, s, a);
   return hipGetLastError();
 }
 
 // FFT_LENGTH 4096: front half (8 segments per frame) -> 4096-point fast convolution -> back half
 static hipError_t launch4096(const RxArgs &a, hipStream_t s) {
   const int grid = (a.nchan + 3) / 4;
-  hipLaunchKernelGGL((rx512_kernel<kModeSsb, false, 1>), dim3(grid), dim3(256), 40960, s, a);
+  hipLaunchKernelGGL((rx512_kernel<kModeSsb, false, 1, false>), dim3(grid), dim3(256), 40960, s, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(fastconv4096_kernel, dim3(a.nchan), dim3(64), kFcLdsFloats * sizeof(float), s, a);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((rx512_kernel<kModeSsb, false, 2>), dim3(grid), dim3(256), 40960, s, a);
+  hipLaunchKernelGGL((rx512_kernel<kModeSsb, false, 2, false>), dim3(grid), dim3(256), 40960, s, a);
   return hipGetLastError();
 }
 

@@ -38,6 +38,7 @@ struct RxArgs {
   float *aud24;            // [nchan][nseg * 256] real: filtered audio @24 kS/s
   const float2 *tab4k;     // tw4096[7][512] | mask4096[8][512] (see kTab4k*)
   int nframes4k;           // number of 4096-frames (= nframes / 8 for the part kernels)
+  int plain;               // 1: unit band/IQ gains and zero IQ phase correction -> specialised kernel
 };
 
 // constant table of the 4096-point fast convolution (float2 units):

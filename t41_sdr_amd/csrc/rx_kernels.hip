@@ -330,6 +330,16 @@ __device__ __forceinline__ CoefPtr fresh_coef(CoefPtr p) {
 }
 
 __device__ __forceinline__ float4 lds4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+// streaming (read-once / write-once) global accesses: nontemporal, so they do not evict the
+// per-channel state and the constant tables from L2 / Infinity Cache
+typedef float f4n __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ldg_stream(const float *p) {
+  const f4n t = __builtin_nontemporal_load(reinterpret_cast<const f4n *>(p));
+  return make_float4(t.x, t.y, t.z, t.w);
+}
+__device__ __forceinline__ void stg_stream(float *p, float4 v) {
+  __builtin_nontemporal_store(f4n{v.x, v.y, v.z, v.w}, reinterpret_cast<f4n *>(p));
+}
 
 typedef float f4v __attribute__((ext_vector_type(4)));
 typedef float f8v __attribute__((ext_vector_type(8)));
@@ -501,10 +511,10 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
       // order): sub-block 0, the I tail for Q's DC-block start state, the delay lines, then
       // sub-block 1.  Input prefetch runs TWO sub-blocks ahead (two register sets, even / odd).
       float4 pI0[2], pI1[2], pQ0[2], pQ1[2];
-      pI0[0] = *reinterpret_cast<const float4 *>(gI + 8 * lane);
-      pI1[0] = *reinterpret_cast<const float4 *>(gI + 8 * lane + 4);
-      pQ0[0] = *reinterpret_cast<const float4 *>(gQ + 8 * lane);
-      pQ1[0] = *reinterpret_cast<const float4 *>(gQ + 8 * lane + 4);
+      pI0[0] = ldg_stream(gI + 8 * lane);
+      pI1[0] = ldg_stream(gI + 8 * lane + 4);
+      pQ0[0] = ldg_stream(gQ + 8 * lane);
+      pQ1[0] = ldg_stream(gQ + 8 * lane + 4);
       const float4 tailI = *reinterpret_cast<const float4 *>(gI + (L - 256) + 4 * lane);
       float4 h1 = make_float4(0, 0, 0, 0), h2 = make_float4(0, 0, 0, 0);
       if (lane < 14) h1 = *reinterpret_cast<const float4 *>(st + kStDec1 + 4 * lane);
@@ -528,10 +538,10 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
         }
       }
       if (f == 0) stage_tables();
-      pI0[1] = *reinterpret_cast<const float4 *>(gI + 512 + 8 * lane);
-      pI1[1] = *reinterpret_cast<const float4 *>(gI + 512 + 8 * lane + 4);
-      pQ0[1] = *reinterpret_cast<const float4 *>(gQ + 512 + 8 * lane);
-      pQ1[1] = *reinterpret_cast<const float4 *>(gQ + 512 + 8 * lane + 4);
+      pI0[1] = ldg_stream(gI + 512 + 8 * lane);
+      pI1[1] = ldg_stream(gI + 512 + 8 * lane + 4);
+      pQ0[1] = ldg_stream(gQ + 512 + 8 * lane);
+      pQ1[1] = ldg_stream(gQ + 512 + 8 * lane + 4);
 
       // ---- delay lines -> LDS (every frame is self-contained: load state, run, store state)
       wave_sync();
@@ -579,10 +589,10 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
           z[7] = cf{pI1[h].w * g_rf_i, pQ1[h].w * g_rf};
           if (s < 2) {  // refill this register set with the sub-block after next
             const int o = 512 * (s + 2) + 8 * lane;
-            pI0[h] = *reinterpret_cast<const float4 *>(gI + o);
-            pI1[h] = *reinterpret_cast<const float4 *>(gI + o + 4);
-            pQ0[h] = *reinterpret_cast<const float4 *>(gQ + o);
-            pQ1[h] = *reinterpret_cast<const float4 *>(gQ + o + 4);
+            pI0[h] = ldg_stream(gI + o);
+            pI1[h] = ldg_stream(gI + o + 4);
+            pQ0[h] = ldg_stream(gQ + o);
+            pQ1[h] = ldg_stream(gQ + o + 4);
           } else if (s == 3) {  // last sub-block: prefetch the overlap-save "previous" block instead
             const cf *ov = reinterpret_cast<const cf *>(st + kStOverlap);
   #pragma unroll
@@ -1057,7 +1067,7 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
       for (int i = 0; i < 8; ++i) {
         const int row = 8 * i + (lane >> 3);
         const float4 t = lds4(lds + 4 * (8 * row + ((lane & 7) ^ (row & 7))));
-        *reinterpret_cast<float4 *>(gO + 256 * i + 4 * lane) = t;
+        stg_stream(gO + 256 * i + 4 * lane, t);
       }
     }
     STAMP(13);  // transposed reads + global stores

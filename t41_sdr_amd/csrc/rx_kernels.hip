@@ -537,7 +537,9 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
           iq_phase_pos = ph > 0.0f ? ph : 0.0f;
         }
       }
+      STAMP(16);  // prologue a: issue + scalar (SMEM) gains
       if (f == 0) stage_tables();
+      STAMP(17);  // prologue b: table staging + workgroup barrier (first vmcnt wait)
       pI0[1] = ldg_stream(gI + 512 + 8 * lane);
       pI1[1] = ldg_stream(gI + 512 + 8 * lane + 4);
       pQ0[1] = ldg_stream(gQ + 512 + 8 * lane);
@@ -547,6 +549,7 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
       wave_sync();
       if (lane < 14) *reinterpret_cast<float4 *>(lds + kX + 2 * xpad(2 * lane)) = h1;
       if (lane < 24) *reinterpret_cast<float4 *>(lds + kY1 + 4 * lane) = h2;
+      STAMP(18);  // prologue c: delay lines -> LDS
       if (f == 0) {
         dphi = uniform_u64(raw_dphi);
         phase0 = uniform_u64(raw_phase);
@@ -568,7 +571,7 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
         dc2 = f2{(g_rf_i != g_rf) ? -dc_carry : dc_carry, dc_highpass_end_state<4>(x, hp4.x, hp4.y)};
       }
 
-      STAMP(15);  // frame prologue: state restore, table staging, Q's DC-block start state
+      STAMP(15);  // prologue d: NCO/DC state uniformisation + Q's DC-block start state
       cf y2[2][2];  // /8 outputs of this frame: m = 128*round + 2*lane + e
       cf v[8];      // FFT registers; v[0..3] = previous block, prefetched below
 

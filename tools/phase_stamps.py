@@ -13,7 +13,9 @@ import t41_sdr_amd as T  # noqa: E402
 NAMES = ["wait loads + gain", "DC high-pass", "NCO + mix", "LDS stage + /4 FIR", "history rolls", "/2 FIR",
          "state save + assemble", "twiddle loads", "forward FFT", "mask + inverse FFT", "demod + x2 staging",
          "x2 interpolator", "x4 interp + transpose writes", "transposed reads + stores",
-         "first sub-block: wait loads", "frame prologue (state, tables, DC prepass)"]
+         "first sub-block: wait loads", "prologue d: uniformise state + DC prepass",
+         "prologue a: issue loads + SMEM gains", "prologue b: table staging + barrier (first vmcnt wait)",
+         "prologue c: delay lines -> LDS"]
 
 
 def main():
@@ -29,7 +31,7 @@ def main():
         rx.ProcessIQData(I, Q)
     torch.cuda.synchronize()
     st = buf[nch * D:].view(torch.int64).view(nch, 64).cpu().numpy().astype(np.float64)
-    tot = st[:, :16].sum(axis=1)
+    tot = st[:, :19].sum(axis=1)
     print("channels %d: mean wave cycles %.0f (min %.0f max %.0f)" % (nch, tot.mean(), tot.min(), tot.max()))
     for p, name in enumerate(NAMES):
         print("  %2d %-30s %8.0f cycles  %5.1f %%" % (p, name, st[:, p].mean(), 100 * st[:, p].mean() / tot.mean()))

@@ -56,6 +56,7 @@ void t41o_default_params(t41o_params *p) {
   p->xmtMode = T41O_SSB_MODE;     /* gwv.cpp:22 */
   p->CWFreqShift = 750;
   p->am_lpf_f0 = 3000;            /* boot band 40M LSB -200/-3000, T41_SDR.ino:560-563 */
+  p->AGC_thresh = 20;             /* bands[] "AGC" column, T41_SDR.ino:145-168 */
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -187,10 +188,82 @@ static int valid_fft_length(int n) { return n == 512 || n == 1024 || n == 2048 |
 /* CalcFilters() Filter.cpp:235-249 -> CalcCplxFIRCoeffs + InitFilterMask (Filter.cpp:260-284)
  * + SetDecIntFilters (Filter.cpp:396-417); NFM re-designs dec1/dec2 every block
  * (Process.cpp:259 -> Filter.cpp:429-438). */
+/* AGCPrep() (DSP_Fn.cpp:444-468) followed by AGCLoadValues() (DSP_Fn.cpp:368-435) for one
+ * AGCMode, as at boot (T41_SDR.ino:791) with AGCMode already read from EEPROM.  The firmware's
+ * globals are history dependent (hang_thresh = 1.0 written by modes 3/4 survives a later switch
+ * to mode 1/2 because only AGCLoadValues() is re-run, MenuProc.cpp:279); this restates the
+ * boot sequence.  Every variable is a float32_t global in the reference. */
+static void agc_load_values(const t41o_params *p, float *agc) {
+  memset(agc, 0, sizeof(float) * T41O_AGC_NCONST);
+  if (p->AGCMode == 0) return;
+  /* AGCPrep */
+  float tau_attack = 0.001;
+  float tau_decay = 0.250;
+  int n_tau = 4;
+  float max_gain = 10000.0;
+  float max_input = 1.0;
+  float out_targ = 1.0;
+  float var_gain = 1.5;
+  float tau_fast_backaverage = 0.250;
+  float tau_fast_decay = 0.005;
+  float pop_ratio = 5.0;
+  float tau_hang_backmult = 0.500;
+  float hangtime = 0.250;
+  float hang_thresh = 0.250;
+  float tau_hang_decay = 0.100;
+  /* AGCLoadValues */
+  float tmp;
+  float sample_rate = (float)SAMPLE_RATE / DF;
+  switch (p->AGCMode) {
+    case 1: hangtime = 2.000; tau_decay = 2.000; break;                     /* agcLONG */
+    case 2: hangtime = 1.000; tau_decay = 0.5; break;                       /* agcSLOW */
+    case 3: hang_thresh = 1.0; hangtime = 0.000; tau_decay = 0.250; break;  /* agcMED */
+    case 4: hang_thresh = 1.0; hangtime = 0.0; tau_decay = 0.050; break;    /* agcFAST */
+    default: break;
+  }
+  max_gain = powf(10.0, (float)p->AGC_thresh / 20.0);
+  int attack_buffsize = (int)ceil(sample_rate * n_tau * tau_attack);
+  float attack_mult = 1.0 - expf(-1.0 / (sample_rate * tau_attack));
+  float decay_mult = 1.0 - expf(-1.0 / (sample_rate * tau_decay));
+  float fast_decay_mult = 1.0 - expf(-1.0 / (sample_rate * tau_fast_decay));
+  float fast_backmult = 1.0 - expf(-1.0 / (sample_rate * tau_fast_backaverage));
+  float onemfast_backmult = 1.0 - fast_backmult;
+  float out_target = out_targ * (1.0 - expf(-(float)n_tau)) * 0.9999;
+  float min_volts = out_target / (var_gain * max_gain);
+  tmp = log10f(out_target / (max_input * var_gain * max_gain));
+  if (tmp == 0.0) tmp = 1e-16;
+  float slope_constant = (out_target * (1.0 - 1.0 / var_gain)) / tmp;
+  float inv_max_input = 1.0 / max_input;
+  tmp = powf(10.0, (hang_thresh - 1.0) / 0.125);
+  float hang_level = (max_input * tmp + (out_target / (var_gain * max_gain)) * (1.0 - tmp)) * 0.637;
+  float hang_backmult = 1.0 - expf(-1.0 / (sample_rate * tau_hang_backmult));
+  float onemhang_backmult = 1.0 - hang_backmult;
+  float hang_decay_mult = 1.0 - expf(-1.0 / (sample_rate * tau_hang_decay));
+
+  agc[T41O_AGC_ATTACK_MULT] = attack_mult;
+  agc[T41O_AGC_DECAY_MULT] = decay_mult;
+  agc[T41O_AGC_FAST_DECAY_MULT] = fast_decay_mult;
+  agc[T41O_AGC_FAST_BACKMULT] = fast_backmult;
+  agc[T41O_AGC_ONEMFAST_BACKMULT] = onemfast_backmult;
+  agc[T41O_AGC_HANG_BACKMULT] = hang_backmult;
+  agc[T41O_AGC_ONEMHANG_BACKMULT] = onemhang_backmult;
+  agc[T41O_AGC_HANG_DECAY_MULT] = hang_decay_mult;
+  agc[T41O_AGC_OUT_TARGET] = out_target;
+  agc[T41O_AGC_MIN_VOLTS] = min_volts;
+  agc[T41O_AGC_SLOPE_CONSTANT] = slope_constant;
+  agc[T41O_AGC_INV_MAX_INPUT] = inv_max_input;
+  agc[T41O_AGC_HANG_LEVEL] = hang_level;
+  agc[T41O_AGC_POP_RATIO] = pop_ratio;
+  agc[T41O_AGC_HANG_COUNT] = (float)(int)(hangtime * SAMPLE_RATE / DF); /* DSP_Fn.cpp:550 */
+  agc[T41O_AGC_ATTACK_BUFFSIZE] = (float)attack_buffsize;
+}
+
 int t41o_design(const t41o_params *p, t41o_coeffs *c) {
   const int N = p->fft_length;
   if (!valid_fft_length(N)) return -1;
+  if (p->AGCMode < 0 || p->AGCMode > 4) return -2;
   memset(c, 0, sizeof(*c));
+  agc_load_values(p, c->agc);
   const int m_NumTaps = N / 2 + 1; /* Filter.cpp:18 */
   float *cI = (float *)calloc((size_t)m_NumTaps, sizeof(float));
   float *cQ = (float *)calloc((size_t)m_NumTaps, sizeof(float));
@@ -395,14 +468,24 @@ struct t41o_channel {
   float wold;                         /* Process.cpp:73 */
   float lp1_state[4];                 /* biquad_lowpass1_state, T41_SDR.ino:373 */
   float nfm_last_i, nfm_last_q;       /* Demod.cpp:221-222 */
+  /* AGC() statics and globals, DSP_Fn.cpp:28-36, 481-492 */
+  uint8_t agc_decay_type, agc_state;
+  float *agc_abs_ring, *agc_ring;     /* [RB_SIZE], [2*RB_SIZE] */
+  float agc_fast_backaverage, agc_hang_backaverage, agc_ring_max, agc_save_volts, agc_volts;
+  int agc_hang_counter, agc_out_index;
+  uint32_t agc_in_index;
+  int agc_in_index_set;               /* AGCLoadValues(): in_index = attack_buffsize + out_index */
   /* working buffers (the reference's globals) */
   float *float_buffer_L, *float_buffer_R, *float_buffer_L_EX, *float_buffer_R_EX;
   float *FFT_buffer, *iFFT_buffer;
   /* taps */
-  float *tap_ncoI, *tap_ncoQ, *tap_decI, *tap_decQ, *tap_ifft, *tap_demod;
+  float *tap_ncoI, *tap_ncoQ, *tap_decI, *tap_decQ, *tap_ifft, *tap_demod, *tap_volts;
 };
 
 static float *fzalloc(size_t n) { return (float *)calloc(n, sizeof(float)); }
+
+/* DSP_Fn.cpp:18-20, 470: RB_SIZE = (int)(24000.0 * 8 * 0.01 + 1) */
+#define AGC_RB_SIZE ((int)(24000.0 * 8 * 0.01 + 1))
 
 t41o_channel *t41o_channel_create(int fft_length) {
   if (!valid_fft_length(fft_length)) return NULL;
@@ -431,6 +514,9 @@ t41o_channel *t41o_channel_create(int fft_length) {
   ch->tap_decQ = fzalloc((size_t)D);
   ch->tap_ifft = fzalloc((size_t)(2 * N));
   ch->tap_demod = fzalloc((size_t)D);
+  ch->tap_volts = fzalloc((size_t)D);
+  ch->agc_abs_ring = fzalloc(AGC_RB_SIZE);
+  ch->agc_ring = fzalloc(2 * AGC_RB_SIZE);
   t41o_channel_reset(ch);
   return ch;
 }
@@ -457,6 +543,9 @@ void t41o_channel_destroy(t41o_channel *ch) {
   free(ch->tap_decQ);
   free(ch->tap_ifft);
   free(ch->tap_demod);
+  free(ch->tap_volts);
+  free(ch->agc_abs_ring);
+  free(ch->agc_ring);
   free(ch);
 }
 
@@ -477,6 +566,19 @@ void t41o_channel_reset(t41o_channel *ch) {
   ch->wold = 0.0f;
   memset(ch->lp1_state, 0, sizeof(ch->lp1_state));
   ch->nfm_last_i = ch->nfm_last_q = 0.0f;
+  /* DSP_Fn.cpp:32-36, 481-492 */
+  ch->agc_decay_type = 0;
+  ch->agc_state = 0;
+  memset(ch->agc_abs_ring, 0, sizeof(float) * AGC_RB_SIZE);
+  memset(ch->agc_ring, 0, sizeof(float) * 2 * AGC_RB_SIZE);
+  ch->agc_fast_backaverage = ch->agc_hang_backaverage = 0;
+  ch->agc_ring_max = 0.0;
+  ch->agc_save_volts = 0.0;
+  ch->agc_volts = 0.0;
+  ch->agc_hang_counter = 0;
+  ch->agc_out_index = -1;
+  ch->agc_in_index = 0;
+  ch->agc_in_index_set = 0;
 }
 
 int t41o_channel_tap(const t41o_channel *ch, int which, float *dst, int maxlen) {
@@ -489,6 +591,7 @@ int t41o_channel_tap(const t41o_channel *ch, int which, float *dst, int maxlen) 
     case T41O_TAP_DEC_Q: src = ch->tap_decQ; n = ch->D; break;
     case T41O_TAP_IFFT: src = ch->tap_ifft; n = 2 * ch->N; break;
     case T41O_TAP_DEMOD: src = ch->tap_demod; n = ch->D; break;
+    case T41O_TAP_AGC_VOLTS: src = ch->tap_volts; n = ch->D; break;
     default: return -1;
   }
   if (n > maxlen) n = maxlen;
@@ -550,6 +653,186 @@ static void AGC_off(float *iFFT_buffer, int N) {
   }
 }
 
+/* Utility.cpp:245-258 */
+static float log10f_fast(float X) {
+  float Y, F;
+  int E;
+  F = frexpf(fabsf(X), &E);
+  Y = 1.23149591368684f;
+  Y *= F;
+  Y += -4.11852516267426f;
+  Y *= F;
+  Y += 6.02197014179219f;
+  Y *= F;
+  Y += -3.13396450166353f;
+  Y += E;
+  return (Y * 0.3010299956639812f);
+}
+
+/* wiring.h min(): the conditional's type is the common type of both operands */
+#define MIN_D(a, b) ((a) < (b) ? (a) : (b))
+
+/* DSP_Fn.cpp:479-632, AGCMode != 0.  Variable names and statement order follow the reference;
+ * its file-scope/static variables live in the channel, its AGCLoadValues() outputs in g[].
+ * pmode = 1 (DSP_Fn.cpp:35): magnitude by sqrtf.  hang_enable = 1 (DSP_Fn.cpp:458). */
+static void AGC_on(t41o_channel *ch, const float *g, float *iFFT_buffer, int FFT_length) {
+  int k;
+  float mult;
+  const unsigned ring_buffsize = AGC_RB_SIZE;
+  float *abs_ring = ch->agc_abs_ring, *ring = ch->agc_ring;
+  float abs_out_sample;
+  float out_sample[2];
+  const int attack_buffsize = (int)g[T41O_AGC_ATTACK_BUFFSIZE];
+  const float attack_mult = g[T41O_AGC_ATTACK_MULT], decay_mult = g[T41O_AGC_DECAY_MULT];
+  const float fast_decay_mult = g[T41O_AGC_FAST_DECAY_MULT];
+  const float fast_backmult = g[T41O_AGC_FAST_BACKMULT];
+  const float onemfast_backmult = g[T41O_AGC_ONEMFAST_BACKMULT];
+  const float hang_backmult = g[T41O_AGC_HANG_BACKMULT];
+  const float onemhang_backmult = g[T41O_AGC_ONEMHANG_BACKMULT];
+  const float hang_decay_mult = g[T41O_AGC_HANG_DECAY_MULT];
+  const float out_target = g[T41O_AGC_OUT_TARGET], min_volts = g[T41O_AGC_MIN_VOLTS];
+  const float slope_constant = g[T41O_AGC_SLOPE_CONSTANT];
+  const float inv_max_input = g[T41O_AGC_INV_MAX_INPUT];
+  const float hang_level = g[T41O_AGC_HANG_LEVEL], pop_ratio = g[T41O_AGC_POP_RATIO];
+  const int hang_enable = 1;
+  uint8_t decay_type = ch->agc_decay_type, state = ch->agc_state;
+  float fast_backaverage = ch->agc_fast_backaverage, hang_backaverage = ch->agc_hang_backaverage;
+  float ring_max = ch->agc_ring_max, save_volts = ch->agc_save_volts, volts = ch->agc_volts;
+  int hang_counter = ch->agc_hang_counter, out_index = ch->agc_out_index;
+  uint32_t in_index = ch->agc_in_index;
+  if (!ch->agc_in_index_set) { /* AGCLoadValues(), DSP_Fn.cpp:410 */
+    in_index = attack_buffsize + out_index;
+    ch->agc_in_index_set = 1;
+  }
+
+  for (unsigned i = 0; i < (unsigned)FFT_length / 2; i++) {
+    if (++out_index >= (int)ring_buffsize) out_index -= ring_buffsize;
+    if (++in_index >= ring_buffsize) in_index -= ring_buffsize;
+
+    out_sample[0] = ring[2 * out_index + 0];
+    out_sample[1] = ring[2 * out_index + 1];
+    abs_out_sample = abs_ring[out_index];
+    ring[2 * in_index + 0] = iFFT_buffer[FFT_length + 2 * i + 0];
+    ring[2 * in_index + 1] = iFFT_buffer[FFT_length + 2 * i + 1];
+    abs_ring[in_index] = sqrtf(ring[2 * in_index + 0] * ring[2 * in_index + 0] +
+                               ring[2 * in_index + 1] * ring[2 * in_index + 1]);
+
+    fast_backaverage = fast_backmult * abs_out_sample + onemfast_backmult * fast_backaverage;
+    hang_backaverage = hang_backmult * abs_out_sample + onemhang_backmult * hang_backaverage;
+
+    if ((abs_out_sample >= ring_max) && (abs_out_sample > 0.0)) {
+      ring_max = 0.0;
+      k = out_index;
+      for (int j = 0; j < attack_buffsize; j++) {
+        if (++k == (int)ring_buffsize) k = 0;
+        if (abs_ring[k] > ring_max) ring_max = abs_ring[k];
+      }
+    }
+    if (abs_ring[in_index] > ring_max) ring_max = abs_ring[in_index];
+
+    if (hang_counter > 0) --hang_counter;
+
+    switch (state) {
+      case 0:
+        if (ring_max >= volts) {
+          volts += (ring_max - volts) * attack_mult;
+        } else {
+          if (volts > pop_ratio * fast_backaverage) {
+            state = 1;
+            volts += (ring_max - volts) * fast_decay_mult;
+          } else {
+            if (hang_enable && (hang_backaverage > hang_level)) {
+              state = 2;
+              hang_counter = (int)g[T41O_AGC_HANG_COUNT];
+              decay_type = 1;
+            } else {
+              state = 3;
+              volts += (ring_max - volts) * decay_mult;
+              decay_type = 0;
+            }
+          }
+        }
+        break;
+      case 1:
+        if (ring_max >= volts) {
+          state = 0;
+          volts += (ring_max - volts) * attack_mult;
+        } else {
+          if (volts > save_volts) {
+            volts += (ring_max - volts) * fast_decay_mult;
+          } else {
+            if (hang_counter > 0) {
+              state = 2;
+            } else {
+              if (decay_type == 0) {
+                state = 3;
+                volts += (ring_max - volts) * decay_mult;
+              } else {
+                state = 4;
+                volts += (ring_max - volts) * hang_decay_mult;
+              }
+            }
+          }
+        }
+        break;
+      case 2:
+        if (ring_max >= volts) {
+          state = 0;
+          save_volts = volts;
+          volts += (ring_max - volts) * attack_mult;
+        } else {
+          if (hang_counter == 0) {
+            state = 4;
+            volts += (ring_max - volts) * hang_decay_mult;
+          }
+        }
+        break;
+      case 3:
+        if (ring_max >= volts) {
+          state = 0;
+          save_volts = volts;
+          volts += (ring_max - volts) * attack_mult;
+        } else {
+          volts += (ring_max - volts) * decay_mult * .05;
+        }
+        break;
+      case 4:
+        if (ring_max >= volts) {
+          state = 0;
+          save_volts = volts;
+          volts += (ring_max - volts) * attack_mult;
+        } else {
+          volts += (ring_max - volts) * hang_decay_mult;
+        }
+        break;
+    }
+    if (volts < min_volts) volts = min_volts; /* no AGC action is taking place */
+    ch->tap_volts[i] = volts;
+
+    mult = (out_target - slope_constant * MIN_D(0.0, log10f_fast(inv_max_input * volts))) / volts;
+    iFFT_buffer[FFT_length + 2 * i + 0] = out_sample[0] * mult;
+    iFFT_buffer[FFT_length + 2 * i + 1] = out_sample[1] * mult;
+  }
+  ch->agc_decay_type = decay_type;
+  ch->agc_state = state;
+  ch->agc_fast_backaverage = fast_backaverage;
+  ch->agc_hang_backaverage = hang_backaverage;
+  ch->agc_ring_max = ring_max;
+  ch->agc_save_volts = save_volts;
+  ch->agc_volts = volts;
+  ch->agc_hang_counter = hang_counter;
+  ch->agc_out_index = out_index;
+  ch->agc_in_index = in_index;
+}
+
+static void AGC(t41o_channel *ch, const t41o_params *p, const t41o_coeffs *c, float *iFFT_buffer,
+                int N) {
+  if (p->AGCMode == 0)
+    AGC_off(iFFT_buffer, N);
+  else
+    AGC_on(ch, c->agc, iFFT_buffer, N);
+}
+
 static void cmplx_mult_cmplx(const float *a, const float *b, float *d, int n) {
   for (int i = 0; i < n; i++) { /* arm_cmplx_mult_cmplx_f32 */
     float ar = a[2 * i], ai = a[2 * i + 1], br = b[2 * i], bi = b[2 * i + 1];
@@ -562,7 +845,7 @@ int t41o_process_frame(t41o_channel *ch, const t41o_params *p, const t41o_coeffs
                        const float *I, const float *Q, float *audio) {
   const int N = ch->N, D = ch->D, L = ch->L;
   if (p->fft_length != N) return -1;
-  if (p->AGCMode != 0) return -2;
+  if (p->AGCMode < 0 || p->AGCMode > 4) return -2;
   const int mode = p->mode;
   if (mode < T41O_DEMOD_USB || mode > T41O_DEMOD_NFM) return -3;
   float *fL = ch->float_buffer_L, *fR = ch->float_buffer_R;
@@ -694,7 +977,7 @@ int t41o_process_frame(t41o_channel *ch, const t41o_params *p, const t41o_coeffs
     t41o_cfft_f32(FFT_buffer, N, 0);                      /* Process.cpp:535 */
     cmplx_mult_cmplx(FFT_buffer, c->mask, iFFT_buffer, N); /* Process.cpp:547 */
     t41o_cfft_f32(iFFT_buffer, N, 1);                     /* Process.cpp:595 */
-    AGC_off(iFFT_buffer, N);                              /* Process.cpp:605 */
+    AGC(ch, p, c, iFFT_buffer, N);                        /* Process.cpp:605 */
   }
 
   /* demodulation, Process.cpp:615-761 */
@@ -738,7 +1021,7 @@ int t41o_process_frame(t41o_channel *ch, const t41o_params *p, const t41o_coeffs
     t41o_cfft_f32(FFT_buffer, N, 0);
     cmplx_mult_cmplx(FFT_buffer, c->mask, iFFT_buffer, N);
     t41o_cfft_f32(iFFT_buffer, N, 1);
-    AGC_off(iFFT_buffer, N);
+    AGC(ch, p, c, iFFT_buffer, N);                        /* Process.cpp:810 */
     for (int i = 0; i < D; i++) fL[i] = iFFT_buffer[N + (i * 2)];
   }
   memcpy(ch->tap_ifft, iFFT_buffer, sizeof(float) * (size_t)(2 * N));

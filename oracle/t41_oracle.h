@@ -52,13 +52,25 @@ typedef struct {
   int32_t RFgain;           /* bands[currentBand].RFgain (int) */
   float   IQAmpCorrectionFactor;   /* gwv.cpp:71 */
   float   IQPhaseCorrectionFactor; /* gwv.cpp:72 */
-  int32_t AGCMode;          /* gwv.cpp:15; only 0 (fixed gain) is restated */
+  int32_t AGCMode;          /* gwv.cpp:15; 0 = fixed gain, 1..4 = long/slow/med/fast (DSP_Fn.cpp:373-402) */
   int32_t audioVolume;      /* gwv.cpp:16 */
   int32_t nfmFilterBW;      /* Filter.cpp:16 */
   int32_t xmtMode;          /* gwv.cpp:22 */
   int32_t CWFreqShift;      /* Freq_Shift.cpp:113-116 */
   int32_t am_lpf_f0;        /* cutoff the AM biquad was designed for at boot, T41_SDR.ino:560-566 (3000) */
+  int32_t AGC_thresh;       /* bands[currentBand].AGC_thresh, SDT.h:190 (20 in every bands[] row) */
 } t41o_params;
+
+/* what AGCPrep() + AGCLoadValues() (DSP_Fn.cpp:368-468) leave in the AGC globals, as f32 */
+enum {
+  T41O_AGC_ATTACK_MULT = 0, T41O_AGC_DECAY_MULT, T41O_AGC_FAST_DECAY_MULT, T41O_AGC_FAST_BACKMULT,
+  T41O_AGC_ONEMFAST_BACKMULT, T41O_AGC_HANG_BACKMULT, T41O_AGC_ONEMHANG_BACKMULT,
+  T41O_AGC_HANG_DECAY_MULT, T41O_AGC_OUT_TARGET, T41O_AGC_MIN_VOLTS, T41O_AGC_SLOPE_CONSTANT,
+  T41O_AGC_INV_MAX_INPUT, T41O_AGC_HANG_LEVEL, T41O_AGC_POP_RATIO,
+  T41O_AGC_HANG_COUNT,      /* (int)(hangtime * SampleRate / DF), DSP_Fn.cpp:550 */
+  T41O_AGC_ATTACK_BUFFSIZE, /* (int)ceil(sample_rate * n_tau * tau_attack) = 97 (f32 product) */
+  T41O_AGC_NCONST
+};
 
 /* Coefficients CalcFilters()/SetDecIntFilters()/InitFilterMask() produce. */
 typedef struct {
@@ -67,6 +79,7 @@ typedef struct {
   float int1[T41O_N_INT1_TAPS];
   float int2[T41O_N_INT2_TAPS];
   float biquad_lowpass1[5];
+  float agc[T41O_AGC_NCONST]; /* zeros when AGCMode == 0 */
   float mask[2 * 4096];     /* FIR_filter_mask, 2*fft_length floats used */
 } t41o_coeffs;
 
@@ -123,7 +136,8 @@ enum {
   T41O_TAP_DEC_I = 2,      /* fft_length/2, after dec2 (+ level adjust in SSB/AM) */
   T41O_TAP_DEC_Q = 3,
   T41O_TAP_IFFT = 4,       /* 2*fft_length interleaved, after AGC */
-  T41O_TAP_DEMOD = 5       /* fft_length/2 audio before interpolation */
+  T41O_TAP_DEMOD = 5,      /* fft_length/2 audio before interpolation */
+  T41O_TAP_AGC_VOLTS = 6   /* fft_length/2: `volts` after every sample of the last AGC() call */
 };
 int t41o_channel_tap(const t41o_channel *ch, int which, float *dst, int maxlen);
 

@@ -25,6 +25,80 @@ def _alpha_beta_mag(i, q):
     return np.where(ai > aq, a * ai + b * aq, a * aq + b * ai)
 
 
+def _log10_fast(x):
+    """Utility.cpp:245-258: cubic in the mantissa, in float64 here"""
+    f, e = np.frexp(abs(x))
+    y = ((1.23149591368684 * f - 4.11852516267426) * f + 6.02197014179219) * f - 3.13396450166353 + e
+    return y * 0.3010299956639812
+
+
+def agc_f64(y, g, trace=None):
+    """AGC() (DSP_Fn.cpp:504-631) on a whole stream of complex samples, float64.
+
+    Written from the algorithm's meaning rather than its ring-buffer mechanics: the output is
+    the input delayed by W = attack_buffsize samples, `ring_max` is the maximum of |y| over the W
+    most recent inputs (the reference keeps it incrementally and rescans when the maximum
+    leaves the window, which is the same thing), the rest is the five-state gain law.
+    g: dict name -> value (tests/oracle_lib.AGC_NAMES)."""
+    W = int(g["attack_buffsize"])
+    n = y.size
+    a = np.abs(y)
+    ap = np.concatenate([np.zeros(W), a])
+    yp = np.concatenate([np.zeros(W, dtype=complex), y])
+    win = np.lib.stride_tricks.sliding_window_view(ap, W)  # win[k] = ap[k : k + W]
+    rmax = win[1:n + 1].max(axis=1)                         # inputs i - W + 1 .. i
+    out = np.empty(n, dtype=complex)
+    fba = hba = volts = save = 0.0
+    state, decay_type, hang = 0, 0, 0
+    for i in range(n):
+        ao = ap[i]  # |input i - W|
+        fba = g["fast_backmult"] * ao + g["onemfast_backmult"] * fba
+        hba = g["hang_backmult"] * ao + g["onemhang_backmult"] * hba
+        r = rmax[i]
+        if hang > 0:
+            hang -= 1
+        rising = r >= volts
+        if rising:
+            if state >= 2:
+                save = volts
+            state = 0
+            volts += (r - volts) * g["attack_mult"]
+        elif state == 0:
+            if volts > g["pop_ratio"] * fba:
+                state = 1
+                volts += (r - volts) * g["fast_decay_mult"]
+            elif hba > g["hang_level"]:
+                state, decay_type, hang = 2, 1, int(g["hang_count"])
+            else:
+                state, decay_type = 3, 0
+                volts += (r - volts) * g["decay_mult"]
+        elif state == 1:
+            if volts > save:
+                volts += (r - volts) * g["fast_decay_mult"]
+            elif hang > 0:
+                state = 2
+            elif decay_type == 0:
+                state = 3
+                volts += (r - volts) * g["decay_mult"]
+            else:
+                state = 4
+                volts += (r - volts) * g["hang_decay_mult"]
+        elif state == 2:
+            if hang == 0:
+                state = 4
+                volts += (r - volts) * g["hang_decay_mult"]
+        elif state == 3:
+            volts += (r - volts) * g["decay_mult"] * 0.05
+        else:
+            volts += (r - volts) * g["hang_decay_mult"]
+        volts = max(volts, g["min_volts"])
+        mult = (g["out_target"] - g["slope_constant"] * min(0.0, _log10_fast(g["inv_max_input"] * volts))) / volts
+        out[i] = yp[i] * mult
+        if trace is not None:
+            trace.append((state, volts))
+    return out
+
+
 def mask_taps(coeffs, N):
     """impulse response the mask represents: N/2+1 complex taps, Q of the last one zeroed"""
     m = np.asarray(coeffs["mask"], dtype=np.float64).reshape(N, 2)
@@ -34,8 +108,12 @@ def mask_taps(coeffs, N):
 
 def run(I, Q, nco_freq, coeffs, *, fft_length=512, mode=0, FLoCut=200, FHiCut=3000,
         rfGainAllBands=1, RFgain=1, iq_amp=1.0, iq_phase=0.0, audioVolume=30,
-        xmtMode=0, CWFreqShift=750):
-    """I, Q: 1-D float arrays, a whole number of frames (4*fft_length each). Returns audio."""
+        xmtMode=0, CWFreqShift=750, agc=None, agc_trace=None):
+    """I, Q: 1-D float arrays, a whole number of frames (4*fft_length each). Returns audio.
+    agc: None = AGCMode 0 (fixed gain 20), else the dict of AGC constants for agc_f64()."""
+    def gain(y):
+        return y * 20.0 if agc is None else agc_f64(y, agc, agc_trace)
+
     N = fft_length
     D = N // 2
     L = 4 * N
@@ -109,7 +187,7 @@ def run(I, Q, nco_freq, coeffs, *, fft_length=512, mode=0, FLoCut=200, FHiCut=30
             li, lq = i_[D // 2 - 1], q_[D // 2 - 1]
             out[f * D:(f + 1) * D] = o
         h = mask_taps(coeffs, N)
-        y = np.convolve(out, h)[:out.size] * 20.0
+        y = gain(np.convolve(out, h)[:out.size])
         aud = y.real
     else:
         fk = (-float(np.float32(FLoCut)) * 0.001) if mode == 1 else (float(np.float32(FHiCut)) * 0.001)
@@ -117,7 +195,7 @@ def run(I, Q, nco_freq, coeffs, *, fft_length=512, mode=0, FLoCut=200, FHiCut=30
         vs = float(np.float32(7.0874 * fk ** (-1.232)))
         z = z * vs
         h = mask_taps(coeffs, N)
-        y = np.convolve(z, h)[:z.size] * 20.0
+        y = gain(np.convolve(z, h)[:z.size])
         if mode in (0, 1):
             aud = y.real.copy()
         else:  # AM

@@ -26,12 +26,26 @@ CASES = {
                               IQAmpCorrectionFactor=1.02, IQPhaseCorrectionFactor=-0.013), [0, 39950]),
     "usb_cw_sidetone": (dict(mode=0, FLoCut=200, FHiCut=3000, xmtMode=1, CWFreqShift=750,
                              IQPhaseCorrectionFactor=0.021), [650, -30000]),
+    # AGC on (DSP_Fn.cpp:504-631): fading signal, attack / fast decay / decay states
+    "usb_agc_long": (dict(mode=0, FLoCut=200, FHiCut=3000, AGCMode=1), [5000, -12350]),
+    "am_agc_fast": (dict(mode=2, FLoCut=-3000, FHiCut=3000, AGCMode=4), [1000, 33300]),
+    "nfm_agc_med": (dict(mode=3, FLoCut=200, FHiCut=3000, AGCMode=3), [2500, -20000]),
 }
+FADE = [(0.3, 2.0), (0.3, 0.05), (0.4, 1.2)]  # AGC cases
+NFRAMES_AGC = 10
 NFRAMES = 3
 L = 2048
 
 
 def make_inputs(name, kw, nco):
+    if kw.get("AGCMode", 0):
+        global NFRAMES
+        keep, NFRAMES = NFRAMES, NFRAMES_AGC
+        try:
+            I, Q = make_inputs(name, {k: v for k, v in kw.items() if k != "AGCMode"}, nco)
+        finally:
+            NFRAMES = keep
+        return siggen.fade(I, Q, FADE)
     nch = len(nco)
     seed = 0x5441315F + sum(ord(c) for c in name)
     if kw["mode"] == 3:  # FM-modulated carriers so the discriminator sees a real signal

@@ -13,7 +13,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 
 DEMOD_USB, DEMOD_LSB, DEMOD_AM, DEMOD_NFM = 0, 1, 2, 3
-TAP_POST_NCO_I, TAP_POST_NCO_Q, TAP_DEC_I, TAP_DEC_Q, TAP_IFFT, TAP_DEMOD = range(6)
+TAP_POST_NCO_I, TAP_POST_NCO_Q, TAP_DEC_I, TAP_DEC_Q, TAP_IFFT, TAP_DEMOD, TAP_AGC_VOLTS = range(7)
+AGC_NAMES = ("attack_mult", "decay_mult", "fast_decay_mult", "fast_backmult", "onemfast_backmult",
+             "hang_backmult", "onemhang_backmult", "hang_decay_mult", "out_target", "min_volts",
+             "slope_constant", "inv_max_input", "hang_level", "pop_ratio", "hang_count", "attack_buffsize")
 
 
 class Params(C.Structure):
@@ -32,6 +35,7 @@ class Params(C.Structure):
         ("xmtMode", C.c_int32),
         ("CWFreqShift", C.c_int32),
         ("am_lpf_f0", C.c_int32),
+        ("AGC_thresh", C.c_int32),
     ]
 
 
@@ -42,6 +46,7 @@ class Coeffs(C.Structure):
         ("int1", C.c_float * 48),
         ("int2", C.c_float * 32),
         ("biquad_lowpass1", C.c_float * 5),
+        ("agc", C.c_float * 16),
         ("mask", C.c_float * (2 * 4096)),
     ]
 
@@ -124,6 +129,7 @@ def coeff_arrays(c, fft_length):
         "int1": np.ctypeslib.as_array(c.int1).copy(),
         "int2": np.ctypeslib.as_array(c.int2).copy(),
         "biquad_lowpass1": np.ctypeslib.as_array(c.biquad_lowpass1).copy(),
+        "agc": np.ctypeslib.as_array(c.agc).copy(),
         "mask": np.ctypeslib.as_array(c.mask)[: 2 * fft_length].copy(),
     }
 

@@ -69,3 +69,22 @@ def make_fm(n_channels, n_samples, nco_hz, seed=0x464D, noise=0.003):
         x = amp * np.exp(1j * ph) + noise * (rng.standard_normal(n_samples) + 1j * rng.standard_normal(n_samples))
         I[c], Q[c] = x.real, x.imag
     return I, Q
+
+
+def envelope_steps(n_samples, segments):
+    """piecewise-constant fading envelope: segments = [(fraction of the stream, amplitude), ...]"""
+    e = np.empty(n_samples, dtype=np.float32)
+    pos = 0
+    for frac, amp in segments:
+        m = int(round(frac * n_samples))
+        e[pos:pos + m] = amp
+        pos += m
+    e[pos:] = segments[-1][1]
+    return e
+
+
+def fade(I, Q, segments):
+    """apply envelope_steps to every channel, clipped to the (-1, 1) range of the q15 front end"""
+    e = envelope_steps(I.shape[-1], segments)
+    return (np.clip(I * e, -0.999, 0.999).astype(np.float32),
+            np.clip(Q * e, -0.999, 0.999).astype(np.float32))

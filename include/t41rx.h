@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define T41RX_ABI_VERSION 1
+#define T41RX_ABI_VERSION 2
 
 /* status codes */
 #define T41RX_OK 0
@@ -66,12 +66,14 @@ typedef struct t41rx_params {
   int32_t RFgain;                  /* bands[currentBand].RFgain, Process.cpp:133 */
   float   IQAmpCorrectionFactor;   /* IQAmpCorrectionFactor[currentBand], gwv.cpp:71 */
   float   IQPhaseCorrectionFactor; /* IQPhaseCorrectionFactor[currentBand], gwv.cpp:72 */
-  int32_t AGCMode;                 /* gwv.cpp:15; 0 = off (fixed_gain 20, DSP_Fn.cpp:494-502) */
+  int32_t AGCMode;                 /* gwv.cpp:15; 0 = off (fixed_gain 20, DSP_Fn.cpp:494-502), 1..4 = long/slow/
+                                      med/fast look-ahead AGC (DSP_Fn.cpp:373-402, 504-631) */
   int32_t audioVolume;             /* gwv.cpp:16, Process.cpp:929 */
   int32_t nfmFilterBW;             /* Filter.cpp:16, Process.cpp:259 */
   int32_t xmtMode;                 /* gwv.cpp:22 */
   int32_t CWFreqShift;             /* Freq_Shift.cpp:113-116 */
   int32_t am_lpf_f0;               /* cutoff biquad_lowpass1 was designed for at boot, T41_SDR.ino:560-566 */
+  int32_t AGC_thresh;              /* bands[currentBand].AGC_thresh [dB], SDT.h:190, DSP_Fn.cpp:408 */
 } t41rx_params;
 
 typedef struct t41rx_ctx t41rx_ctx; /* opaque: coefficient arrays + per-channel state + device buffers */
@@ -92,7 +94,9 @@ void t41rx_default_params(t41rx_params *p);
  * behind, serialised as one blob:
  *   header (8 x int32: magic, abi, fft_length, mode, 4 reserved) |
  *   FIR_dec1_coeffs[28] | FIR_dec2_coeffs[46] | FIR_int1_coeffs[48] | FIR_int2_coeffs[32] |
- *   biquad_lowpass1_coeffs[5] | scalars[11] | FIR_filter_mask[2*fft_length]      (all f32)
+ *   biquad_lowpass1_coeffs[5] | scalars[11] | AGC constants[16] (what AGCPrep() +
+ *   AGCLoadValues() leave behind, DSP_Fn.cpp:368-468; zeros for AGCMode 0) |
+ *   FIR_filter_mask[2*fft_length]                                                (all f32)
  * This blob is what rank 0 broadcasts over RCCL after a filter change. */
 size_t t41rx_coeff_blob_bytes(int fft_length);
 int    t41rx_design_coeffs(const t41rx_params *p, void *blob, size_t blob_bytes);

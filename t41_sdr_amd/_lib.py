@@ -32,6 +32,7 @@ class Params(C.Structure):
         ("xmtMode", C.c_int32),
         ("CWFreqShift", C.c_int32),
         ("am_lpf_f0", C.c_int32),
+        ("AGC_thresh", C.c_int32),
     ]
 
 

@@ -145,6 +145,49 @@ void biquad_lowpass(float out[5], float f0, float q, float fs) {
   out[4] = (-1.0 + alpha) * scale;
 }
 
+// The AGC's derived constants: AGCPrep() (DSP_Fn.cpp:444-468) then AGCLoadValues()
+// (DSP_Fn.cpp:368-435) for one AGCMode, i.e. the boot sequence (T41_SDR.ino:791).  In the
+// firmware a later mode change re-runs AGCLoadValues() only, so hang_thresh = 1.0 written by
+// modes 3 / 4 would survive a switch back to 1 / 2; a context always gets the boot values.
+// Every quantity is a float32_t global there; unsuffixed literals are double.
+void agc_constants(const t41rx_params &p, float *out) {
+  if (p.AGCMode == 0) return;  // stays zero
+  const float tau_attack = 0.001, tau_fast_backaverage = 0.250, tau_fast_decay = 0.005;
+  const float tau_hang_backmult = 0.500, tau_hang_decay = 0.100;
+  const float max_input = 1.0, out_targ = 1.0, var_gain = 1.5, pop_ratio = 5.0;
+  const int n_tau = 4;
+  float tau_decay = 0.250, hangtime = 0.250, hang_thresh = 0.250;
+  switch (p.AGCMode) {
+    case 1: hangtime = 2.000; tau_decay = 2.000; break;
+    case 2: hangtime = 1.000; tau_decay = 0.5; break;
+    case 3: hang_thresh = 1.0; hangtime = 0.000; tau_decay = 0.250; break;
+    default: hang_thresh = 1.0; hangtime = 0.0; tau_decay = 0.050; break;
+  }
+  const float sample_rate = (float)kSampleRate / kDF;
+  const float max_gain = powf(10.0, (float)p.AGC_thresh / 20.0);
+  auto one_minus_exp = [&](float tau) { return (float)(1.0 - expf(-1.0 / (sample_rate * tau))); };
+  out[kAgcAttackBuffsize] = (float)(int)std::ceil(sample_rate * n_tau * tau_attack);
+  out[kAgcAttackMult] = one_minus_exp(tau_attack);
+  out[kAgcDecayMult] = one_minus_exp(tau_decay);
+  out[kAgcFastDecayMult] = one_minus_exp(tau_fast_decay);
+  out[kAgcFastBackmult] = one_minus_exp(tau_fast_backaverage);
+  out[kAgcOnemFastBackmult] = 1.0 - out[kAgcFastBackmult];
+  out[kAgcHangBackmult] = one_minus_exp(tau_hang_backmult);
+  out[kAgcOnemHangBackmult] = 1.0 - out[kAgcHangBackmult];
+  out[kAgcHangDecayMult] = one_minus_exp(tau_hang_decay);
+  const float out_target = out_targ * (1.0 - expf(-(float)n_tau)) * 0.9999;
+  out[kAgcOutTarget] = out_target;
+  out[kAgcMinVolts] = out_target / (var_gain * max_gain);
+  float tmp = log10f(out_target / (max_input * var_gain * max_gain));
+  if (tmp == 0.0) tmp = 1e-16;
+  out[kAgcSlopeConstant] = (out_target * (1.0 - 1.0 / var_gain)) / tmp;
+  out[kAgcInvMaxInput] = 1.0 / max_input;
+  tmp = powf(10.0, (hang_thresh - 1.0) / 0.125);
+  out[kAgcHangLevel] = (max_input * tmp + (out_target / (var_gain * max_gain)) * (1.0 - tmp)) * 0.637;
+  out[kAgcPopRatio] = pop_ratio;
+  out[kAgcHangCount] = (float)(int)(hangtime * kSampleRate / kDF);
+}
+
 }  // namespace
 
 bool params_valid(const t41rx_params &p, const char **why) {
@@ -165,6 +208,8 @@ bool params_valid(const t41rx_params &p, const char **why) {
   if (p.nfmFilterBW <= 0 || p.nfmFilterBW > 96000) return fail("nfmFilterBW out of range");
   if (p.xmtMode < T41RX_SSB_MODE || p.xmtMode > T41RX_DATA_MODE) return fail("bad xmtMode");
   if (p.am_lpf_f0 <= 0) return fail("am_lpf_f0 must be > 0");
+  if (p.AGCMode < 0 || p.AGCMode > 4) return fail("AGCMode must be 0 (off) .. 4 (fast)");
+  if (p.AGC_thresh < -40 || p.AGC_thresh > 120) return fail("AGC_thresh out of -40..120 dB");
   return true;
 }
 
@@ -214,6 +259,8 @@ int design_blob(const t41rx_params &p, void *blob, size_t blob_bytes) {
     kaiser_lowpass(v.dec1, kDec1Taps, (float)p.nfmFilterBW, kAtt, (float)kSampleRate);
     kaiser_lowpass(v.dec2, kDec2Taps, (float)p.nfmFilterBW, kAtt, (float)(kSampleRate / kDF1));
   }
+
+  agc_constants(p, v.agc);
 
   // --- per-call scalars ---
   float *s = v.scalars;

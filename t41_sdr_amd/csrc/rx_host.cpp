@@ -125,6 +125,7 @@ int upload_coeffs(t41rx_ctx *ctx) {
   std::memcpy(dc.int2, v.int2, sizeof(float) * kInt2Taps);
   std::memcpy(dc.lp1, v.lp1, sizeof(float) * 5);
   std::memcpy(dc.sc, v.scalars, sizeof(float) * kNumScalars);
+  std::memcpy(dc.agc, v.agc, sizeof(float) * kNumAgc);
   HIP_TRY(hipMemcpy(ctx->d_coef, &dc, sizeof(dc), hipMemcpyHostToDevice));
 
   if (N != 512 && N != 4096) return fail(T41RX_ERR_UNSUPPORTED, "only fft_length 512 and 4096 have kernels");
@@ -241,6 +242,7 @@ void t41rx_default_params(t41rx_params *p) {
   p->xmtMode = T41RX_SSB_MODE;       // gwv.cpp:22
   p->CWFreqShift = 750;
   p->am_lpf_f0 = 3000;               // boot band 40 m: max(FHiCut, -FLoCut) = 3000
+  p->AGC_thresh = 20;                // bands[] "AGC" column, T41_SDR.ino:145-168
 }
 
 size_t t41rx_coeff_blob_bytes(int fft_length) {
@@ -262,7 +264,7 @@ int t41rx_create(t41rx_ctx **out, int device_id, int n_channels, const t41rx_par
   if (n_channels <= 0) return fail(T41RX_ERR_ARG, "n_channels must be > 0");
   const char *why = nullptr;
   if (!params_valid(*p, &why)) return fail(T41RX_ERR_ARG, why ? why : "bad params");
-  if (p->AGCMode != 0) return fail(T41RX_ERR_UNSUPPORTED, "AGCMode != 0 (look-ahead AGC) is not built yet");
+  if (p->AGCMode != 0 && p->fft_length != 512) return fail(T41RX_ERR_UNSUPPORTED, "AGC on is built for fft_length 512 only");
   if (!t41rx_supported_fft_length(p->fft_length)) return fail(T41RX_ERR_UNSUPPORTED, "no kernel for this fft_length");
   if (p->fft_length == 4096 && !(p->mode == T41RX_DEMOD_USB || p->mode == T41RX_DEMOD_LSB))
     return fail(T41RX_ERR_UNSUPPORTED, "fft_length 4096 is built for USB/LSB only");
@@ -316,7 +318,7 @@ int t41rx_set_params(t41rx_ctx *ctx, const t41rx_params *p) {
   const char *why = nullptr;
   if (!params_valid(*p, &why)) return fail(T41RX_ERR_ARG, why ? why : "bad params");
   if (p->fft_length != ctx->params.fft_length) return fail(T41RX_ERR_ARG, "fft_length cannot change on a live context");
-  if (p->AGCMode != 0) return fail(T41RX_ERR_UNSUPPORTED, "AGCMode != 0 is not built yet");
+  if (p->AGCMode != 0 && p->fft_length != 512) return fail(T41RX_ERR_UNSUPPORTED, "AGC on is built for fft_length 512 only");
   if (p->fft_length == 4096 && !(p->mode == T41RX_DEMOD_USB || p->mode == T41RX_DEMOD_LSB))
     return fail(T41RX_ERR_UNSUPPORTED, "fft_length 4096 is built for USB/LSB only");
   std::vector<float> nb(ctx->blob.size());
@@ -423,6 +425,9 @@ int t41rx_process_device(t41rx_ctx *ctx, const float *dI, const float *dQ, float
     const float gi = iq_on ? sc[kScBandGain] * sc[kScNegIqAmp] : sc[kScBandGain];
     a.plain = ((gi == 1.0f || (iq_on && gi == -1.0f)) && sc[kScBandGain] == 1.0f && (!iq_on || sc[kScIqPhase] == 0.0f)) ? 1 : 0;
   }
+  a.agc = ctx->params.AGCMode != 0 ? 1 : 0;
+  if (a.agc && (int)blob_view(ctx->blob.data()).agc[kAgcAttackBuffsize] != kAgcDelay)
+    return fail(T41RX_ERR_STATE, "coefficient blob carries an AGC look-ahead the kernel is not built for");
   a.dbg_nco = ctx->dbg_nco;
   a.dbg_dec = ctx->dbg_dec;
   a.dbg_demod = ctx->dbg_demod;

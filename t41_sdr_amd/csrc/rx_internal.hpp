@@ -29,12 +29,21 @@ enum Scalar {
   kScIqCorrOn = 7,    // 1 when mode in {USB, LSB, AM}, Process.cpp:165-173
   kScSideTone = 8,    // sideToneShift [Hz], Freq_Shift.cpp:108-120
 };
+// what AGCPrep() + AGCLoadValues() (DSP_Fn.cpp:368-468) leave in the AGC globals
+constexpr int kNumAgc = 16;
+enum AgcConst {
+  kAgcAttackMult = 0, kAgcDecayMult, kAgcFastDecayMult, kAgcFastBackmult, kAgcOnemFastBackmult,
+  kAgcHangBackmult, kAgcOnemHangBackmult, kAgcHangDecayMult, kAgcOutTarget, kAgcMinVolts,
+  kAgcSlopeConstant, kAgcInvMaxInput, kAgcHangLevel, kAgcPopRatio,
+  kAgcHangCount,       // (int)(hangtime * SampleRate / DF), DSP_Fn.cpp:550
+  kAgcAttackBuffsize,  // (int)ceil(sample_rate * n_tau * tau_attack), DSP_Fn.cpp:409 (= 97)
+};
 struct BlobView {
   int32_t *header;
-  float *dec1, *dec2, *int1, *int2, *lp1, *scalars, *mask;
+  float *dec1, *dec2, *int1, *int2, *lp1, *scalars, *agc, *mask;
 };
 constexpr size_t blob_floats(int fft_length) {
-  return kBlobHeaderInts + kDec1Taps + kDec2Taps + kInt1Taps + kInt2Taps + 5 + kNumScalars +
+  return kBlobHeaderInts + kDec1Taps + kDec2Taps + kInt1Taps + kInt2Taps + 5 + kNumScalars + kNumAgc +
          2 * (size_t)fft_length;
 }
 inline BlobView blob_view(void *blob) {
@@ -47,7 +56,8 @@ inline BlobView blob_view(void *blob) {
   v.int2 = v.int1 + kInt1Taps;
   v.lp1 = v.int2 + kInt2Taps;
   v.scalars = v.lp1 + 5;
-  v.mask = v.scalars + kNumScalars;
+  v.agc = v.scalars + kNumScalars;
+  v.mask = v.agc + kNumAgc;
   return v;
 }
 
@@ -64,6 +74,7 @@ struct DevCoef {
   float int2[kInt2Taps];
   float lp1[8];    // 5 used
   float sc[16];    // Scalar enum
+  float agc[16];   // AgcConst enum
 };
 
 // per-channel NCO constants, recomputed on the host when NCOFreq changes (set_nco_freq)
@@ -94,6 +105,18 @@ struct NcoState {
   uint64_t phase;  // arg(Osc_Vect_Q + j Osc_Vect_I) in turns, 0.64 fixed point
   double r;        // |Osc_Vect|
 };
-constexpr size_t state_floats(int fft_length) { return (size_t)kStOverlap + (size_t)fft_length; }
+// AGC (DSP_Fn.cpp:504-631), after the overlap block: the look-ahead delay line and the statics.
+// The reference's ring holds 1921 entries of which attack_buffsize = 97 are live; 100 are kept
+// (16-byte alignment) as interleaved (re, im), oldest first.
+constexpr int kAgcDelay = 97;   // attack_buffsize the kernel is built for
+constexpr int kAgcHist = 100;   // complex samples kept
+constexpr int kAgcHistFloats = 2 * kAgcHist;
+// 8 words behind the history: fast_backaverage, hang_backaverage, volts, save_volts (f32),
+// state, decay_type, hang_counter (int32), pad
+constexpr int kAgcScalars = 8;
+constexpr int kAgcStFba = 0, kAgcStHba = 1, kAgcStVolts = 2, kAgcStSave = 3, kAgcStState = 4, kAgcStDecayType = 5,
+              kAgcStHangCounter = 6;
+constexpr size_t st_agc(int fft_length) { return (size_t)kStOverlap + (size_t)fft_length; }
+constexpr size_t state_floats(int fft_length) { return st_agc(fft_length) + kAgcHistFloats + kAgcScalars; }
 
 }  // namespace t41

@@ -416,6 +416,209 @@ __device__ __forceinline__ NcoPtr fresh_nco(NcoPtr p) {
   return p;
 }
 
+// ------------------------------------------------------------------------------------------
+// AGC on (AGCMode 1..4): AGC(), DSP_Fn.cpp:504-631
+// ------------------------------------------------------------------------------------------
+// What the reference does per 24 kS/s sample: push the new (I, Q) into a ring, pop the one from
+// attack_buffsize = 97 samples ago, keep ring_max = max |z| over the 97 newest entries (kept
+// incrementally there, rescanned when the maximum leaves: the same value), run two one-pole
+// averages of |popped|, step a five-state attack / hang / decay law for `volts` against
+// ring_max, and scale the popped sample by a gain computed from volts.
+// Here: everything that is a function of the samples alone (magnitudes, the sliding maximum,
+// the b*x terms of the averages, the gain from volts, the scaling) is done by the whole wave,
+// four consecutive samples per lane.  What is inherently serial -- 256 steps of the volts law
+// and the two averages, which must keep the reference's f32 rounding step by step (the slow
+// decay moves volts by a few ulps per sample, so any reassociation drifts by percents over a
+// second) -- runs as a scalar chain, one LANE per channel: lanes 0..3 of the workgroup's first
+// wave take the four channels of the workgroup between two workgroup barriers.
+// LDS (floats, in the wave's slice):
+constexpr int kAgZ = 0;     // (re, im)[356]: [0..99] the last 100 inputs, [100 + i] this frame's input i
+constexpr int kAgA = 712;   // |z|[356], same indexing
+constexpr int kAgG = 1068;  // max of every aligned group of four |z| (89 used)
+constexpr int kAgR = 1160;  // ring_max[256]; the chain replaces it by volts[256]
+constexpr int kAgP = 1416;  // (fast_backmult, hang_backmult) * abs_out_sample, [256] pairs
+constexpr int kAgS = 1928;  // the 8 state words (rx_internal.hpp: kAgcSt*)
+static_assert(kAgS + kAgcScalars <= kLdsFloatsPerWave, "AGC scratch must fit the wave slice");
+static_assert(kAgcDelay == 97 && kAgcHist == 100, "window arithmetic below is written for 97 / 100");
+constexpr bool kAgcCoop = true;
+
+// DSP_Fn.cpp:520-523 (pmode = 1): separate roundings, correctly rounded square root
+__device__ __forceinline__ float agc_mag(cf z) {
+#pragma clang fp contract(off)
+  const float a = z.x * z.x, b = z.y * z.y;
+  return __builtin_sqrtf(a + b);
+}
+
+// DSP_Fn.cpp:627: mult = (out_target - slope_constant * min(0.0, log10f_fast(inv_max_input * volts))) / volts
+// (double arithmetic from the min() on: its 0.0 literal promotes), log10f_fast = Utility.cpp:245-258
+__device__ __forceinline__ float agc_mult(float volts, float inv_max_input, float out_target, float slope_constant) {
+#pragma clang fp contract(off)
+  const float t = fabsf(inv_max_input * volts);
+  const float F = __builtin_amdgcn_frexp_mantf(t);
+  const int E = __builtin_amdgcn_frexp_expf(t);
+  float Y = 1.23149591368684f;
+  Y *= F;
+  Y += -4.11852516267426f;
+  Y *= F;
+  Y += 6.02197014179219f;
+  Y *= F;
+  Y += -3.13396450166353f;
+  Y += (float)E;
+  const float lg = Y * 0.3010299956639812f;
+  const double m = (0.0 < (double)lg) ? 0.0 : (double)lg;
+  return (float)(((double)out_target - (double)slope_constant * m) / (double)volts);
+}
+
+// The serial part for ONE channel per lane: sl = that channel's LDS slice.
+__device__ __noinline__ void agc_chain(float *sl, CoefPtr cf0) {
+#pragma clang fp contract(off)
+  // (an out-of-line function receives its pointers in VGPRs: make the address scalar again)
+  const CoefPtr c = (CoefPtr)uniform_u64((uint64_t)cf0);
+  const float attack_mult = c->agc[kAgcAttackMult], decay_mult = c->agc[kAgcDecayMult];
+  const float fast_decay_mult = c->agc[kAgcFastDecayMult], hang_decay_mult = c->agc[kAgcHangDecayMult];
+  const float onemfast_backmult = c->agc[kAgcOnemFastBackmult], onemhang_backmult = c->agc[kAgcOnemHangBackmult];
+  const float min_volts = c->agc[kAgcMinVolts], hang_level = c->agc[kAgcHangLevel], pop_ratio = c->agc[kAgcPopRatio];
+  const int hang_count = (int)c->agc[kAgcHangCount];
+  const float4 sf = lds4(sl + kAgS);
+  const int4 si = *reinterpret_cast<const int4 *>(sl + kAgS + 4);
+  float fast_backaverage = sf.x, hang_backaverage = sf.y, volts = sf.z, save_volts = sf.w;
+  int state = si.x, decay_type = si.y, hang_counter = si.z;
+  for (int b = 0; b < 64; ++b) {
+    const float4 r4 = lds4(sl + kAgR + 4 * b);
+    const float4 pa = lds4(sl + kAgP + 8 * b), pb = lds4(sl + kAgP + 8 * b + 4);
+    const float rm[4] = {r4.x, r4.y, r4.z, r4.w};
+    const float pf[4] = {pa.x, pa.z, pb.x, pb.z}, ph[4] = {pa.y, pa.w, pb.y, pb.w};
+    float vo[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float ring_max = rm[k];
+      fast_backaverage = pf[k] + onemfast_backmult * fast_backaverage;  // :525
+      hang_backaverage = ph[k] + onemhang_backmult * hang_backaverage;  // :526
+      if (hang_counter > 0) --hang_counter;                              // :543
+      if (ring_max >= volts) {  // every state attacks the same way; 2, 3, 4 remember where from
+        if (state >= 2) save_volts = volts;
+        state = 0;
+        volts += (ring_max - volts) * attack_mult;
+      } else if (state == 0) {  // :549-566
+        if (volts > pop_ratio * fast_backaverage) {
+          state = 1;
+          volts += (ring_max - volts) * fast_decay_mult;
+        } else if (hang_backaverage > hang_level) {  // hang_enable = 1, :458
+          state = 2;
+          hang_counter = hang_count;
+          decay_type = 1;
+        } else {
+          state = 3;
+          volts += (ring_max - volts) * decay_mult;
+          decay_type = 0;
+        }
+      } else if (state == 1) {  // :569-590
+        if (volts > save_volts) {
+          volts += (ring_max - volts) * fast_decay_mult;
+        } else if (hang_counter > 0) {
+          state = 2;
+        } else if (decay_type == 0) {
+          state = 3;
+          volts += (ring_max - volts) * decay_mult;
+        } else {
+          state = 4;
+          volts += (ring_max - volts) * hang_decay_mult;
+        }
+      } else if (state == 2) {  // :593-604
+        if (hang_counter == 0) {
+          state = 4;
+          volts += (ring_max - volts) * hang_decay_mult;
+        }
+      } else if (state == 3) {  // :607-615; the .05 literal is a double
+        volts = (float)((double)volts + (double)((ring_max - volts) * decay_mult) * .05);
+      } else {  // :618-626
+        volts += (ring_max - volts) * hang_decay_mult;
+      }
+      if (volts < min_volts) volts = min_volts;  // :629
+      vo[k] = volts;
+    }
+    *reinterpret_cast<float4 *>(sl + kAgR + 4 * b) = make_float4(vo[0], vo[1], vo[2], vo[3]);
+  }
+  *reinterpret_cast<float4 *>(sl + kAgS) = make_float4(fast_backaverage, hang_backaverage, volts, save_volts);
+  *reinterpret_cast<int4 *>(sl + kAgS + 4) = make_int4(state, decay_type, hang_counter, 0);
+}
+
+// v[4 + j] = inverse FFT output sample i = lane + 64 j (the valid half); agst = this lane's
+// float4 of the channel's AGC record (lanes 0..49 delay line, 50..51 state words).
+// og[k] = AGC output sample 4 lane + k.
+__device__ __forceinline__ void agc_apply(const cf (&v)[8], float4 agst, float *lds, float *smem, float *st_ag,
+                                          CoefPtr cf0, int lane, int wv, int nvalid, cf (&og)[4]) {
+  wave_sync();
+  if (lane < 50) *reinterpret_cast<float4 *>(lds + kAgZ + 4 * lane) = agst;
+  else if (lane < 52) *reinterpret_cast<float4 *>(lds + kAgS + 4 * (lane - 50)) = agst;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    *reinterpret_cast<cf *>(lds + kAgZ + 2 * (100 + lane + 64 * j)) = v[4 + j];
+    lds[kAgA + 100 + lane + 64 * j] = agc_mag(v[4 + j]);
+  }
+  if (lane < 50) *reinterpret_cast<float2 *>(lds + kAgA + 2 * lane) = make_float2(agc_mag(cf{agst.x, agst.y}), agc_mag(cf{agst.z, agst.w}));
+  wave_sync();
+  {  // maxima of the aligned groups of four
+    float4 t = lds4(lds + kAgA + 4 * lane);
+    lds[kAgG + lane] = fmaxf(fmaxf(t.x, t.y), fmaxf(t.z, t.w));
+    if (lane < 25) {
+      t = lds4(lds + kAgA + 256 + 4 * lane);
+      lds[kAgG + 64 + lane] = fmaxf(fmaxf(t.x, t.y), fmaxf(t.z, t.w));
+    }
+  }
+  wave_sync();
+  {
+    // sample i = 4 lane + j pops entry [i + 3] and its window is entries [i + 4 .. i + 100]:
+    // the tail of group lane + 1, the 23 whole groups lane + 2 .. lane + 24, the head of the
+    // lane's own new group
+    const CoefPtr c = fresh_coef(cf0);
+    const float fast_backmult = c->agc[kAgcFastBackmult], hang_backmult = c->agc[kAgcHangBackmult];
+    const float4 nv = lds4(lds + kAgA + 100 + 4 * lane);
+    const float4 g1 = lds4(lds + kAgA + 4 + 4 * lane);
+    const float ao0 = lds[kAgA + 3 + 4 * lane];
+    float C = lds[kAgG + lane + 2];
+#pragma unroll
+    for (int q = 3; q <= 24; ++q) C = fmaxf(C, lds[kAgG + lane + q]);
+    const float s3 = g1.w, s2 = fmaxf(g1.z, s3), s1 = fmaxf(g1.y, s2), s0 = fmaxf(g1.x, s1);
+    const float p0 = nv.x, p1 = fmaxf(p0, nv.y), p2 = fmaxf(p1, nv.z), p3 = fmaxf(p2, nv.w);
+    *reinterpret_cast<float4 *>(lds + kAgR + 4 * lane) =
+        make_float4(fmaxf(fmaxf(s0, C), p0), fmaxf(fmaxf(s1, C), p1), fmaxf(fmaxf(s2, C), p2), fmaxf(fmaxf(s3, C), p3));
+    const float ao[4] = {ao0, g1.x, g1.y, g1.z};
+    {
+#pragma clang fp contract(off)
+      *reinterpret_cast<float4 *>(lds + kAgP + 8 * lane) =
+          make_float4(fast_backmult * ao[0], hang_backmult * ao[0], fast_backmult * ao[1], hang_backmult * ao[1]);
+      *reinterpret_cast<float4 *>(lds + kAgP + 8 * lane + 4) =
+          make_float4(fast_backmult * ao[2], hang_backmult * ao[2], fast_backmult * ao[3], hang_backmult * ao[3]);
+    }
+  }
+  if (kAgcCoop) {
+    __syncthreads();
+    if (wv == 0 && lane < nvalid) agc_chain(smem + kLdsTabFloats + lane * kLdsFloatsPerWave, cf0);
+    __syncthreads();
+  } else {
+    wave_sync();
+    agc_chain(lds, cf0);
+    wave_sync();
+  }
+  {
+    const CoefPtr c = fresh_coef(cf0);
+    const float inv_max_input = c->agc[kAgcInvMaxInput], out_target = c->agc[kAgcOutTarget], slope_constant = c->agc[kAgcSlopeConstant];
+    const float4 vv = lds4(lds + kAgR + 4 * lane);
+    const float vk[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const cf z = *reinterpret_cast<const cf *>(lds + kAgZ + 2 * (3 + 4 * lane + k));
+      const float mult = agc_mult(vk[k], inv_max_input, out_target, slope_constant);
+      og[k] = cf{z.x * mult, z.y * mult};
+    }
+  }
+  // the record for the next frame: the newest 100 inputs and the state words
+  if (lane < 50) *reinterpret_cast<float4 *>(st_ag + 4 * lane) = lds4(lds + kAgZ + 512 + 4 * lane);
+  else if (lane < 52) *reinterpret_cast<float4 *>(st_ag + kAgcHistFloats + 4 * (lane - 50)) = lds4(lds + kAgS + 4 * (lane - 50));
+  wave_sync();
+}
+
 constexpr int kModeSsb = 0, kModeAm = 1, kModeNfm = 2;  // kernel template MODE
 
 // ------------------------------------------------------------------------------------------
@@ -430,7 +633,8 @@ constexpr int kModeSsb = 0, kModeAm = 1, kModeNfm = 2;  // kernel template MODE
 // thing left, the reference's I <- -I (Process.cpp:166), is folded into the sign of the RF-gain
 // multiply of I, which is exact because the DC high-pass in between is linear and negation is exact
 // (the I chain's carry is negated with it).
-template <int MODE, bool DEBUG, int PART, bool PLAIN>
+// AGC: AGCMode != 0 (see agc_apply); the demodulator then works on lane-contiguous samples.
+template <int MODE, bool DEBUG, int PART, bool PLAIN, bool AGC = false>
 __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int L = 2048, D = 256, N = 512;
@@ -494,7 +698,9 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
     const float *__restrict__ gQ = a.Q + fbase;
     float *__restrict__ gO = a.out + fbase;
 
-    float aud[4];                            // 4 demodulated samples @24 kS/s: i = lane + 64 j (AM: 4 lane + j)
+    constexpr bool CONTIG = (MODE == kModeAm) || AGC;  // aud[j] = sample 4 lane + j instead of lane + 64 j
+    float aud[4];                            // 4 demodulated samples @24 kS/s
+    float4 agst = make_float4(0, 0, 0, 0);   // AGC record (delay line + state words), one float4 per lane
     float4 hist1 = make_float4(0, 0, 0, 0);  // x2 interpolator history (lanes 0..5)
     float hist2 = 0.0f;                      // x4 interpolator history (lane i = entry i)
     if (PART == 2) {
@@ -736,6 +942,7 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
       if (lane < 24) *reinterpret_cast<float4 *>(st + kStDec2 + 4 * lane) = lds4(lds + kY1 + 4 * lane);
       if (lane < 6) hist1 = *reinterpret_cast<const float4 *>(st + kStInt1 + 4 * lane);
       if (lane < 8) hist2 = st[kStInt2 + lane];
+      if (AGC && lane < 52) agst = *reinterpret_cast<const float4 *>(st + st_agc(kStateN) + 4 * lane);
       wave_sync();
 
       // ---- level adjust (Process.cpp:481-492)
@@ -841,27 +1048,36 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
         }
       }
 
-      // ---- AGC off: fixed gain on the valid half (DSP_Fn.cpp:494-502); SSB/NFM: audio = Re
+      // ---- AGC (Process.cpp:605 / :810).  Off: fixed gain on the valid half (DSP_Fn.cpp:494-502).
+      // SSB/NFM: audio = Re
       const float fixed_gain = fresh_coef(cf0)->sc[kScFixedGain];
+      cf og[4];
+      if (AGC) {
+        const int left = a.nchan - 4 * (int)blockIdx.x;
+        agc_apply(v, agst, lds, smem, st + st_agc(kStateN), cf0, lane, wv, left < 4 ? left : 4, og);
+      }
       if (MODE != kModeAm) {
   #pragma unroll
-        for (int j = 0; j < 4; ++j) aud[j] = fixed_gain * v[4 + j].x;
+        for (int j = 0; j < 4; ++j) aud[j] = AGC ? og[j].x : fixed_gain * v[4 + j].x;
       } else {
         // ---- AM (Process.cpp:697-707): AlphaBetaMag envelope (Utility.cpp:269-285), DC removal
         // w = m + 0.99 w_old, y = w - w_old, then biquad_lowpass1 (DF1).  Both recurrences run as
         // wave scans over lane-contiguous chunks of 4 samples.
   #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const cf g = v[4 + j] * splat(fixed_gain);
+          const cf g = AGC ? og[j] : v[4 + j] * splat(fixed_gain);
           const float ai = fabsf(g.x), aq = fabsf(g.y);
           const float hi = fmaxf(ai, aq), lo = fminf(ai, aq);
           aud[j] = 0.960433870103f * hi + 0.397824734759f * lo;
         }
-        wave_sync();
+        float4 m4 = make_float4(aud[0], aud[1], aud[2], aud[3]);
+        if (!AGC) {  // lane + 64 j -> 4 lane + j
+          wave_sync();
   #pragma unroll
-        for (int j = 0; j < 4; ++j) lds[24 + lane + 64 * j] = aud[j];
-        wave_sync();
-        const float4 m4 = lds4(lds + 24 + 4 * lane);
+          for (int j = 0; j < 4; ++j) lds[24 + lane + 64 * j] = aud[j];
+          wave_sync();
+          m4 = lds4(lds + 24 + 4 * lane);
+        }
         const float m[4] = {m4.x, m4.y, m4.z, m4.w};
         float *ms = st + kStMisc;
         // -- DC block.  The reference accumulates w ~ 100x the signal in f32; here the scan runs in
@@ -969,7 +1185,7 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
       if (DEBUG && a.dbg_demod) {
         float *dm = a.dbg_demod + ((size_t)ch * a.nframes + f) * D;
   #pragma unroll
-        for (int j = 0; j < 4; ++j) dm[(MODE == kModeAm) ? 4 * lane + j : lane + 64 * j] = aud[j];
+        for (int j = 0; j < 4; ++j) dm[CONTIG ? 4 * lane + j : lane + 64 * j] = aud[j];
       }
 
     }
@@ -984,7 +1200,7 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
     wave_sync();
     {
       if (lane < 6) *reinterpret_cast<float4 *>(lds + 4 * lane) = hist1;
-      if (MODE == kModeAm) {
+      if (CONTIG) {
         *reinterpret_cast<float4 *>(lds + 24 + 4 * lane) = make_float4(aud[0], aud[1], aud[2], aud[3]);
       } else {
 #pragma unroll
@@ -1191,7 +1407,14 @@ static hipError_t launch512(const RxArgs &a, hipStream_t s, bool debug) {
   // per CU, so a 4096-channel batch is one full, balanced wave of work on 256 CUs.
   const size_t lds = 40960;
   static_assert((kLdsTabFloats + 4 * kLdsFloatsPerWave) * sizeof(float) <= 40960, "LDS slice too large");
-  if (debug)
+  if (a.agc) {
+    if (debug)
+      hipLaunchKernelGGL((rx512_kernel<MODE, true, 0, false, true>), dim3(grid), dim3(256), lds, s, a);
+    else if (a.plain)
+      hipLaunchKernelGGL((rx512_kernel<MODE, false, 0, true, true>), dim3(grid), dim3(256), lds, s, a);
+    else
+      hipLaunchKernelGGL((rx512_kernel<MODE, false, 0, false, true>), dim3(grid), dim3(256), lds, s, a);
+  } else if (debug)
     hipLaunchKernelGGL((rx512_kernel<MODE, true, 0, false>), dim3(grid), dim3(256), lds, s, a);
   else if (a.plain)
     hipLaunchKernelGGL((rx512_kernel<MODE, false, 0, true>), dim3(grid), dim3(256), lds, s, a);

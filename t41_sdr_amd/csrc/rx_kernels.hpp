@@ -39,6 +39,7 @@ struct RxArgs {
   const float2 *tab4k;     // tw4096[7][512] | mask4096[8][512] (see kTab4k*)
   int nframes4k;           // number of 4096-frames (= nframes / 8 for the part kernels)
   int plain;               // 1: unit band/IQ gains and zero IQ phase correction -> specialised kernel
+  int agc;                 // 1: AGCMode != 0 (look-ahead AGC, DSP_Fn.cpp:504-631)
 };
 
 // constant table of the 4096-point fast convolution (float2 units):

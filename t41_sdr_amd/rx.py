@@ -45,7 +45,7 @@ def blob_fields(blob, fft_length):
     o = 8
     out = {}
     for name, n in (("dec1", 28), ("dec2", 46), ("int1", 48), ("int2", 32), ("biquad_lowpass1", 5),
-                    ("scalars", 11), ("mask", 2 * fft_length)):
+                    ("scalars", 11), ("agc", 16), ("mask", 2 * fft_length)):
         out[name] = f[o:o + n]
         o += n
     return out

@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported(T):
     assert not missing, "declared in include/t41rx.h but not exported: %s" % missing
     from t41_sdr_amd import _lib
     assert declared == set(_lib.SYMBOLS), "python binding and header disagree"
-    assert lib.t41rx_abi_version() == 1
+    assert lib.t41rx_abi_version() == 2
 
 
 def test_params_struct_layout_matches_header(T):
@@ -51,13 +51,17 @@ def test_params_struct_layout_matches_header(T):
     dict(mode=0, FLoCut=100, FHiCut=11000),  # > 10 kHz: resampler design caps at 10 kHz (Filter.cpp:408)
     dict(mode=0, FLoCut=400, FHiCut=600, fft_length=4096),
     dict(mode=0, FLoCut=200, FHiCut=3000, fft_length=1024),
+    dict(mode=0, FLoCut=200, FHiCut=3000, AGCMode=1),
+    dict(mode=2, FLoCut=-3000, FHiCut=3000, AGCMode=2, AGC_thresh=30),
+    dict(mode=3, FLoCut=200, FHiCut=3000, AGCMode=3),
+    dict(mode=1, FLoCut=-3000, FHiCut=-200, AGCMode=4, AGC_thresh=10),
 ])
 def test_designer_matches_oracle(T, kw):
     p = T.default_params(**kw)
     N = p.fft_length
     got = T.blob_fields(T.design_coeffs(p), N)
     ref = O.coeff_arrays(O.design(O.default_params(**kw)), N)
-    for k in ("dec1", "dec2", "int1", "int2", "biquad_lowpass1"):
+    for k in ("dec1", "dec2", "int1", "int2", "biquad_lowpass1", "agc"):
         assert np.array_equal(got[k], ref[k]), k  # same f32 arithmetic -> bit-exact
     # the mask goes through a different f32 FFT decomposition: rounding-level agreement
     assert np.abs(got["mask"] - ref["mask"]).max() < 4e-7 * np.abs(ref["mask"]).max()
@@ -82,13 +86,13 @@ def test_design_rejects_bad_arguments(T):
     lib = T.load()
     p = T.default_params()
     n = lib.t41rx_coeff_blob_bytes(512)
-    assert n == 4 * (8 + 28 + 46 + 48 + 32 + 5 + 11 + 1024)
+    assert n == 4 * (8 + 28 + 46 + 48 + 32 + 5 + 11 + 16 + 1024)
     assert lib.t41rx_coeff_blob_bytes(500) == 0
     buf = (C.c_uint8 * n)()
     assert lib.t41rx_design_coeffs(C.byref(p), buf, n - 1) == _lib.ERR_ARG
     assert lib.t41rx_design_coeffs(None, buf, n) == _lib.ERR_ARG
     for bad in (dict(fft_length=300), dict(mode=9), dict(FLoCut=3000, FHiCut=200), dict(audioVolume=101),
-                dict(mode=1, FLoCut=200, FHiCut=3000), dict(FHiCut=20000)):
+                dict(mode=1, FLoCut=200, FHiCut=3000), dict(FHiCut=20000), dict(AGCMode=5), dict(AGCMode=-1)):
         with pytest.raises(T.T41RxError) as e:
             T.design_coeffs(T.default_params(**bad))
         assert e.value.status == _lib.ERR_ARG

@@ -102,6 +102,70 @@ def test_parity_nfm(T):
     assert np.array_equal(got, split)
 
 
+# ---- AGC on (DSP_Fn.cpp:504-631).  Fading signals that drive the gain law through
+# attack, fast decay, hang, decay and hang-decay; 10 channels = two full workgroups + a ragged one.
+AGC_CASES = [
+    (2, 0, 140, [(0.15, 2.5), (0.75, 0.05), (0.1, 2.5)]),   # slow: all five states (hang expires)
+    (1, 0, 40, [(0.5, 2.5), (0.3, 0.05), (0.2, 1.5)]),      # long: attack, fast decay, hang
+    (3, 1, 40, [(0.4, 2.5), (0.3, 0.05), (0.3, 1.6)]),      # med, LSB: attack, fast decay, decay
+    (4, 2, 30, [(0.4, 2.0), (0.3, 0.05), (0.3, 1.6)]),      # fast, AM
+    (1, 3, 12, [(0.4, 1.0), (0.3, 0.3), (0.3, 1.0)]),       # NFM: AGC acts on the filtered audio
+]
+
+
+@pytest.mark.parametrize("agcmode,mode,nfr,segs", AGC_CASES, ids=["slow-usb", "long-usb", "med-lsb", "fast-am", "long-nfm"])
+def test_parity_agc(T, agcmode, mode, nfr, segs):
+    nch = 10
+    nco = siggen.nco_grid(nch, seed=5 + agcmode)
+    if mode == 3:
+        I, Q = siggen.make_fm(nch, nfr * L, nco, seed=3)
+    else:
+        I, Q = siggen.make_iq(nch, nfr * L, nco, mode=mode, seed=5, audio_hz=(400.0, 2500.0))
+    I, Q = siggen.fade(I, Q, segs)
+    flo, fhi = {0: (200, 3000), 1: (-3000, -200), 2: (-3000, 3000), 3: (200, 3000)}[mode]
+    kw = dict(mode=mode, AGCMode=agcmode, FLoCut=flo, FHiCut=fhi)
+    got, rx = gpu_run(T, kw, nco, I, Q)
+    ob = O.OracleBatch(O.default_params(**kw), np.asarray(nco, np.int32))
+    ref = ob.process(I, Q, nthreads=8)
+    err = siggen.block_rel_err(got, ref, L)
+    assert np.isfinite(got).all()
+    assert err.max() <= (AM_TOL if mode == 2 else TOL), (err.max(), np.unravel_index(err.argmax(), err.shape))
+    # the gain-law state itself: `volts` after the last sample (state record: 768 + 200 history floats, word 2)
+    st = rx.get_state().view(np.float32).reshape(nch, -1)
+    volts_ref = np.array([ob.tap(c, O.TAP_AGC_VOLTS, 256)[-1] for c in range(nch)])
+    assert np.abs(st[:, 768 + 200 + 2] - volts_ref).max() <= 1e-5 * volts_ref.max()
+    # frame by frame == one call, bit for bit
+    split, _ = gpu_run(T, kw, nco, I, Q, split=[0, L, 5 * L, nfr * L])
+    assert np.array_equal(got, split)
+
+
+def test_agc_mode_change_and_reset(T):
+    """AGCMode is a parameter like the filter edges: switching it mid-stream keeps the delay line and
+    the gain state (the firmware only re-runs AGCLoadValues()), reset() returns to power-on"""
+    nch, nfr = 6, 8
+    nco = siggen.nco_grid(nch, seed=77)
+    I, Q = siggen.make_iq(nch, nfr * L, nco, mode=0, seed=78)
+    I, Q = siggen.fade(I, Q, [(0.5, 2.0), (0.5, 0.1)])
+    kw = dict(mode=0, AGCMode=3)
+    first, rx = gpu_run(T, kw, nco, I, Q)
+    rx.reset()
+    import torch
+    again = rx.ProcessIQData(torch.from_numpy(I).cuda(), torch.from_numpy(Q).cuda()).cpu().numpy()
+    assert np.array_equal(first, again)
+    # oracle with the same mid-stream switch 3 -> 4 after frame 4
+    ob = O.OracleBatch(O.default_params(**kw), np.asarray(nco, np.int32))
+    r1 = ob.process(np.ascontiguousarray(I[:, :4 * L]), np.ascontiguousarray(Q[:, :4 * L]))
+    ob.p.AGCMode = 4
+    ob.redesign()
+    r2 = ob.process(np.ascontiguousarray(I[:, 4 * L:]), np.ascontiguousarray(Q[:, 4 * L:]))
+    rx.reset()
+    g1 = rx.ProcessIQData(torch.from_numpy(I[:, :4 * L].copy()).cuda(), torch.from_numpy(Q[:, :4 * L].copy()).cuda()).cpu().numpy()
+    rx.CalcFilters(AGCMode=4)
+    g2 = rx.ProcessIQData(torch.from_numpy(I[:, 4 * L:].copy()).cuda(), torch.from_numpy(Q[:, 4 * L:].copy()).cuda()).cpu().numpy()
+    err = siggen.block_rel_err(np.concatenate([g1, g2], 1), np.concatenate([r1, r2], 1), L)
+    assert err.max() <= TOL, err.max()
+
+
 def test_parity_fft4096(T):
     """BASELINE config 4 (synthetic generalisation): FFT_LENGTH 4096, 16384-sample
     frames, 2049-tap narrow USB filter (400..600 Hz), three-kernel pipeline"""
@@ -262,7 +326,8 @@ def test_argument_errors(T):
     with pytest.raises(T.T41RxError) as e:
         rx.SetNCOFreq(np.full(4, 200000))
     assert e.value.status == _lib.ERR_ARG
-    for unsupported in (dict(AGCMode=1), dict(fft_length=1024), dict(fft_length=4096, mode=3)):
+    for unsupported in (dict(AGCMode=1, fft_length=4096, FLoCut=400, FHiCut=600), dict(fft_length=1024),
+                        dict(fft_length=4096, mode=3)):
         with pytest.raises(T.T41RxError) as e:
             T.RxChain(4, T.default_params(**unsupported))
         assert e.value.status == _lib.ERR_UNSUPPORTED

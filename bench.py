@@ -43,6 +43,9 @@ WORKLOADS = {
     "nfm": dict(batch=4096, fft=512, kw=dict(mode=3, FLoCut=200, FHiCut=3000, nfmFilterBW=12000),
                 name="configs[2]: NFM path as the firmware runs it (quadri-correlator + limiter + real overlap-save audio "
                      "filter), 4096 channels x 2048 samples per step"),
+    "ssb_agc": dict(batch=4096, fft=512, kw=dict(mode=0, FLoCut=200, FHiCut=3000, AGCMode=1),
+                    name="configs[1] with the firmware's default AGCMode = 1 (look-ahead AGC, DSP_Fn.cpp:504-631) instead of "
+                         "the fixed gain: 4096 channels x 2048 samples per step (SURVEY 8f rank 1)"),
     "fft4096": dict(batch=1024, fft=4096, kw=dict(mode=0, FLoCut=400, FHiCut=600),
                     name="configs[3]: PSK31-like narrow USB filter, 4096-pt fast-conv (synthetic generalisation), "
                          "1024 channels x 16384 samples per step"),
@@ -156,7 +159,8 @@ def main():
         N_CHANNELS = wl["batch"]
     FFT_LENGTH = wl["fft"]
     FRAME_LEN = 4 * FFT_LENGTH
-    params_kw = dict(fft_length=FFT_LENGTH, rfGainAllBands=1, RFgain=1, AGCMode=0, audioVolume=30, **wl["kw"])
+    params_kw = dict(fft_length=FFT_LENGTH, rfGainAllBands=1, RFgain=1, AGCMode=0, audioVolume=30)
+    params_kw.update(wl["kw"])
     params = T.default_params(**params_kw)
     rng = np.random.default_rng(1000 + rank)
     nco = (rng.integers(-860, 801, N_CHANNELS) * 50).astype(np.int32)  # [-43000, 40000] Hz, 50 Hz steps

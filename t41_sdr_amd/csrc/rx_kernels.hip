@@ -75,8 +75,12 @@ __device__ __forceinline__ void wave_sync() {
     if (lane == (p)) stamp_acc += t_ - stamp_last;                                   \
     stamp_last = t_;                                                                 \
   } while (0)
+#define STAMP_PARAMS , unsigned long long &stamp_acc, unsigned long long &stamp_last
+#define STAMP_ARGS , stamp_acc, stamp_last
 #else
 #define STAMP(p) do {} while (0)
+#define STAMP_PARAMS
+#define STAMP_ARGS
 #endif
 
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -440,7 +444,10 @@ constexpr int kAgP = 1416;  // (fast_backmult, hang_backmult) * abs_out_sample, 
 constexpr int kAgS = 1928;  // the 8 state words (rx_internal.hpp: kAgcSt*)
 static_assert(kAgS + kAgcScalars <= kLdsFloatsPerWave, "AGC scratch must fit the wave slice");
 static_assert(kAgcDelay == 97 && kAgcHist == 100, "window arithmetic below is written for 97 / 100");
-constexpr bool kAgcCoop = true;
+#ifndef T41RX_AGC_COOP
+#define T41RX_AGC_COOP 1
+#endif
+constexpr bool kAgcCoop = T41RX_AGC_COOP;
 
 // DSP_Fn.cpp:520-523 (pmode = 1): separate roundings, correctly rounded square root
 __device__ __forceinline__ float agc_mag(cf z) {
@@ -470,84 +477,217 @@ __device__ __forceinline__ float agc_mult(float volts, float inv_max_input, floa
 }
 
 // The serial part for ONE channel per lane: sl = that channel's LDS slice.
-__device__ __noinline__ void agc_chain(float *sl, CoefPtr cf0) {
+//
+// A single wave runs it, so what counts is the number of instructions per step (one VALU issue per
+// 4 cycles) and the length of the dependent chain volts -> volts.  Steps are taken four at a
+// time.  agc_fast_block() assumes the common case -- every lane either attacks (ring_max >=
+// volts: same update from every state, then state 0) or stays in its decay state -- with
+// predicated straight-line code, and reports whether any lane met something else (a decision of
+// state 0, fast decay reaching save_volts, the hang counter expiring).  Only then the block is
+// redone by agc_slow_block(), the reference's switch statement as written.  Both produce the same
+// f32 values step by step.
+struct AgcState {
+  float fast_backaverage, hang_backaverage, volts, save_volts;
+  int state, decay_type, hang_counter;
+};
+struct AgcConsts {
+  float attack_mult, decay_mult, fast_decay_mult, hang_decay_mult, onemfast_backmult, onemhang_backmult;
+  float min_volts, hang_level, pop_ratio;
+  int hang_count;
+};
+
+// DSP_Fn.cpp:525-629 for four consecutive samples, any state sequence
+__device__ __forceinline__ void agc_slow_block(AgcState &st, const AgcConsts &g, const float (&rm)[4],
+                                               const float (&pf)[4], const float (&ph)[4], float (&vo)[4]) {
 #pragma clang fp contract(off)
-  // (an out-of-line function receives its pointers in VGPRs: make the address scalar again)
-  const CoefPtr c = (CoefPtr)uniform_u64((uint64_t)cf0);
-  const float attack_mult = c->agc[kAgcAttackMult], decay_mult = c->agc[kAgcDecayMult];
-  const float fast_decay_mult = c->agc[kAgcFastDecayMult], hang_decay_mult = c->agc[kAgcHangDecayMult];
-  const float onemfast_backmult = c->agc[kAgcOnemFastBackmult], onemhang_backmult = c->agc[kAgcOnemHangBackmult];
-  const float min_volts = c->agc[kAgcMinVolts], hang_level = c->agc[kAgcHangLevel], pop_ratio = c->agc[kAgcPopRatio];
-  const int hang_count = (int)c->agc[kAgcHangCount];
+  float fast_backaverage = st.fast_backaverage, hang_backaverage = st.hang_backaverage;
+  float volts = st.volts, save_volts = st.save_volts;
+  int state = st.state, decay_type = st.decay_type, hang_counter = st.hang_counter;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float ring_max = rm[k];
+    fast_backaverage = pf[k] + g.onemfast_backmult * fast_backaverage;  // :525
+    hang_backaverage = ph[k] + g.onemhang_backmult * hang_backaverage;  // :526
+    if (hang_counter > 0) --hang_counter;                                // :543
+    if (ring_max >= volts) {  // every state attacks the same way; 2, 3, 4 remember where from
+      if (state >= 2) save_volts = volts;
+      state = 0;
+      volts += (ring_max - volts) * g.attack_mult;
+    } else if (state == 0) {  // :549-566
+      if (volts > g.pop_ratio * fast_backaverage) {
+        state = 1;
+        volts += (ring_max - volts) * g.fast_decay_mult;
+      } else if (hang_backaverage > g.hang_level) {  // hang_enable = 1, :458
+        state = 2;
+        hang_counter = g.hang_count;
+        decay_type = 1;
+      } else {
+        state = 3;
+        volts += (ring_max - volts) * g.decay_mult;
+        decay_type = 0;
+      }
+    } else if (state == 1) {  // :569-590
+      if (volts > save_volts) {
+        volts += (ring_max - volts) * g.fast_decay_mult;
+      } else if (hang_counter > 0) {
+        state = 2;
+      } else if (decay_type == 0) {
+        state = 3;
+        volts += (ring_max - volts) * g.decay_mult;
+      } else {
+        state = 4;
+        volts += (ring_max - volts) * g.hang_decay_mult;
+      }
+    } else if (state == 2) {  // :593-604
+      if (hang_counter == 0) {
+        state = 4;
+        volts += (ring_max - volts) * g.hang_decay_mult;
+      }
+    } else if (state == 3) {  // :607-615; the .05 literal is a double
+      volts = (float)((double)volts + (double)((ring_max - volts) * g.decay_mult) * .05);
+    } else {  // :618-626
+      volts += (ring_max - volts) * g.hang_decay_mult;
+    }
+    if (volts < g.min_volts) volts = g.min_volts;  // :629
+    vo[k] = volts;
+  }
+  st = AgcState{fast_backaverage, hang_backaverage, volts, save_volts, state, decay_type, hang_counter};
+}
+
+// What the straight-line path needs to know about a lane's state, kept in registers between
+// blocks (recomputed only after a slow block):
+//   stay    : volts += (ring_max - volts) * stay while the lane remains in its decay state
+//             (state 2 = hang: 0, volts rests)
+//   thr     : state 1 leaves fast decay once volts <= save_volts; -inf for the others
+//   in0     : state 0 -- any step that does not attack is a decision, i.e. not for this path
+//   from234 : an attack out of states 2, 3, 4 records save_volts
+//   is3     : state 3 adds its decay step in double (DSP_Fn.cpp:614)
+struct AgcLane {
+  float stay, thr;
+  bool in0, from234, is3, is2;
+};
+__device__ __forceinline__ AgcLane agc_lane_of(const AgcState &st, const AgcConsts &g) {
+  const int s = st.state;
+  AgcLane d;
+  d.stay = g.hang_decay_mult;
+  d.stay = (s == 1) ? g.fast_decay_mult : d.stay;
+  d.stay = (s == 2) ? 0.0f : d.stay;
+  d.stay = (s == 3) ? g.decay_mult : d.stay;
+  d.thr = (s == 1) ? st.save_volts : -__builtin_inff();
+  d.in0 = s == 0;
+  d.from234 = s >= 2;
+  d.is3 = s == 3;
+  d.is2 = s == 2;
+  return d;
+}
+
+// The same four steps under the assumption described above; returns false for a lane whose
+// assumption failed somewhere in the block (its results are then meaningless).
+// HAS3: some lane is in state 3.
+template <bool HAS3>
+__device__ __forceinline__ bool agc_fast_block(AgcState &st, AgcLane &d, const AgcConsts &g, const float (&rm)[4],
+                                               const float (&pf)[4], const float (&ph)[4], float (&vo)[4]) {
+#pragma clang fp contract(off)
+  // the hang counter cannot run out inside the block if more than four steps are left.
+  // (bool logic is written with & | ~ on purpose: && || ?: on bools make the compiler build 0/1
+  // integers in VGPRs; this way the masks stay in SGPR pairs and cost no VALU issue)
+  bool ok = !(d.is2 & (st.hang_counter <= 4));
+  bool in0 = d.in0;
+  const bool from234 = d.from234;  // (such a lane starts with in0 = false)
+  float volts = st.volts, save_volts = st.save_volts;
+  f2 back = f2{st.fast_backaverage, st.hang_backaverage};
+  const f2 onem = f2{g.onemfast_backmult, g.onemhang_backmult};
+  float attack_mult = g.attack_mult, min_volts = g.min_volts;
+  asm volatile("" : "+v"(attack_mult), "+v"(min_volts));  // v_cndmask / v_max operands: keep them in VGPRs
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const f2 aged = onem * back;
+    back = f2{pf[k], ph[k]} + aged;
+    const float ring_max = rm[k];
+    const bool ge = ring_max >= volts;
+    const bool gt = volts > d.thr;
+    ok = ok & (ge | (!in0 & gt));
+    save_volts = (ge & from234 & !in0) ? volts : save_volts;  // the first attack out of 2, 3, 4
+    const float step = (ring_max - volts) * (ge ? attack_mult : d.stay);
+    float next = volts + step;
+    if (HAS3) {
+      const float next3 = (float)((double)volts + (double)step * .05);
+      next = (ge | !d.is3) ? next : next3;
+    }
+    in0 = in0 | ge;
+    asm("v_max_f32 %0, %1, %2" : "=v"(volts) : "v"(next), "v"(min_volts));  // :629 (no NaNs here)
+    vo[k] = volts;
+  }
+  st.fast_backaverage = back.x;
+  st.hang_backaverage = back.y;
+  st.volts = volts;
+  st.save_volts = save_volts;
+  st.state = in0 ? 0 : st.state;
+  const int hc = st.hang_counter - 4;
+  st.hang_counter = hc > 0 ? hc : 0;
+  d.from234 = from234 & !in0;
+  d.in0 = in0;
+  return ok;
+}
+
+__device__ __forceinline__ void agc_chain(float *sl, CoefPtr cf0, int lane STAMP_PARAMS) {
+  const CoefPtr c = fresh_coef(cf0);
+  AgcConsts g;
+  g.attack_mult = c->agc[kAgcAttackMult];
+  g.decay_mult = c->agc[kAgcDecayMult];
+  g.fast_decay_mult = c->agc[kAgcFastDecayMult];
+  g.hang_decay_mult = c->agc[kAgcHangDecayMult];
+  g.onemfast_backmult = c->agc[kAgcOnemFastBackmult];
+  g.onemhang_backmult = c->agc[kAgcOnemHangBackmult];
+  g.min_volts = c->agc[kAgcMinVolts];
+  g.hang_level = c->agc[kAgcHangLevel];
+  g.pop_ratio = c->agc[kAgcPopRatio];
+  g.hang_count = (int)c->agc[kAgcHangCount];
   const float4 sf = lds4(sl + kAgS);
   const int4 si = *reinterpret_cast<const int4 *>(sl + kAgS + 4);
-  float fast_backaverage = sf.x, hang_backaverage = sf.y, volts = sf.z, save_volts = sf.w;
-  int state = si.x, decay_type = si.y, hang_counter = si.z;
+  AgcState st{sf.x, sf.y, sf.z, sf.w, si.x, si.y, si.z};
+  AgcLane d = agc_lane_of(st, g);
+  float4 nr4 = lds4(sl + kAgR), npa = lds4(sl + kAgP), npb = lds4(sl + kAgP + 4);
   for (int b = 0; b < 64; ++b) {
-    const float4 r4 = lds4(sl + kAgR + 4 * b);
-    const float4 pa = lds4(sl + kAgP + 8 * b), pb = lds4(sl + kAgP + 8 * b + 4);
+    const float4 r4 = nr4, pa = npa, pb = npb;
+    if (b < 63) {  // the next four steps' operands, ahead of the dependent chain
+      nr4 = lds4(sl + kAgR + 4 * b + 4);
+      npa = lds4(sl + kAgP + 8 * b + 8);
+      npb = lds4(sl + kAgP + 8 * b + 12);
+    }
     const float rm[4] = {r4.x, r4.y, r4.z, r4.w};
     const float pf[4] = {pa.x, pa.z, pb.x, pb.z}, ph[4] = {pa.y, pa.w, pb.y, pb.w};
     float vo[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float ring_max = rm[k];
-      fast_backaverage = pf[k] + onemfast_backmult * fast_backaverage;  // :525
-      hang_backaverage = ph[k] + onemhang_backmult * hang_backaverage;  // :526
-      if (hang_counter > 0) --hang_counter;                              // :543
-      if (ring_max >= volts) {  // every state attacks the same way; 2, 3, 4 remember where from
-        if (state >= 2) save_volts = volts;
-        state = 0;
-        volts += (ring_max - volts) * attack_mult;
-      } else if (state == 0) {  // :549-566
-        if (volts > pop_ratio * fast_backaverage) {
-          state = 1;
-          volts += (ring_max - volts) * fast_decay_mult;
-        } else if (hang_backaverage > hang_level) {  // hang_enable = 1, :458
-          state = 2;
-          hang_counter = hang_count;
-          decay_type = 1;
-        } else {
-          state = 3;
-          volts += (ring_max - volts) * decay_mult;
-          decay_type = 0;
-        }
-      } else if (state == 1) {  // :569-590
-        if (volts > save_volts) {
-          volts += (ring_max - volts) * fast_decay_mult;
-        } else if (hang_counter > 0) {
-          state = 2;
-        } else if (decay_type == 0) {
-          state = 3;
-          volts += (ring_max - volts) * decay_mult;
-        } else {
-          state = 4;
-          volts += (ring_max - volts) * hang_decay_mult;
-        }
-      } else if (state == 2) {  // :593-604
-        if (hang_counter == 0) {
-          state = 4;
-          volts += (ring_max - volts) * hang_decay_mult;
-        }
-      } else if (state == 3) {  // :607-615; the .05 literal is a double
-        volts = (float)((double)volts + (double)((ring_max - volts) * decay_mult) * .05);
-      } else {  // :618-626
-        volts += (ring_max - volts) * hang_decay_mult;
-      }
-      if (volts < min_volts) volts = min_volts;  // :629
-      vo[k] = volts;
+    AgcState t = st;
+    AgcLane dt = d;
+    bool ok;
+    if (__builtin_amdgcn_ballot_w64(d.is3 && !d.in0) != 0)
+      ok = agc_fast_block<true>(t, dt, g, rm, pf, ph, vo);
+    else
+      ok = agc_fast_block<false>(t, dt, g, rm, pf, ph, vo);
+    if (__builtin_amdgcn_ballot_w64(!ok) != 0) {  // some lane changes state other than by an attack
+      STAMP(24);  // chain: fast blocks
+      t = st;
+      agc_slow_block(t, g, rm, pf, ph, vo);
+      dt = agc_lane_of(t, g);
+      STAMP(25);  // chain: slow blocks
+#ifdef T41RX_STAMP
+      if (lane == 26) stamp_acc += 1;  // number of slow blocks
+#endif
     }
+    st = t;
+    d = dt;
     *reinterpret_cast<float4 *>(sl + kAgR + 4 * b) = make_float4(vo[0], vo[1], vo[2], vo[3]);
   }
-  *reinterpret_cast<float4 *>(sl + kAgS) = make_float4(fast_backaverage, hang_backaverage, volts, save_volts);
-  *reinterpret_cast<int4 *>(sl + kAgS + 4) = make_int4(state, decay_type, hang_counter, 0);
+  *reinterpret_cast<float4 *>(sl + kAgS) = make_float4(st.fast_backaverage, st.hang_backaverage, st.volts, st.save_volts);
+  *reinterpret_cast<int4 *>(sl + kAgS + 4) = make_int4(st.state, st.decay_type, st.hang_counter, 0);
 }
 
 // v[4 + j] = inverse FFT output sample i = lane + 64 j (the valid half); agst = this lane's
 // float4 of the channel's AGC record (lanes 0..49 delay line, 50..51 state words).
 // og[k] = AGC output sample 4 lane + k.
 __device__ __forceinline__ void agc_apply(const cf (&v)[8], float4 agst, float *lds, float *smem, float *st_ag,
-                                          CoefPtr cf0, int lane, int wv, int nvalid, cf (&og)[4]) {
+                                          CoefPtr cf0, int lane, int wv, int nvalid, cf (&og)[4] STAMP_PARAMS) {
   wave_sync();
   if (lane < 50) *reinterpret_cast<float4 *>(lds + kAgZ + 4 * lane) = agst;
   else if (lane < 52) *reinterpret_cast<float4 *>(lds + kAgS + 4 * (lane - 50)) = agst;
@@ -592,13 +732,25 @@ __device__ __forceinline__ void agc_apply(const cf (&v)[8], float4 agst, float *
           make_float4(fast_backmult * ao[2], hang_backmult * ao[2], fast_backmult * ao[3], hang_backmult * ao[3]);
     }
   }
+  STAMP(19);  // AGC: magnitudes, look-ahead maximum
   if (kAgcCoop) {
     __syncthreads();
-    if (wv == 0 && lane < nvalid) agc_chain(smem + kLdsTabFloats + lane * kLdsFloatsPerWave, cf0);
+    STAMP(20);  // AGC: barrier 1
+    // wave 0 runs the chains: the hardware places the first waves of the workgroups sharing a CU
+    // on different SIMDs (HW_ID dump of the -DT41RX_STAMP build), so the four chains of a CU do
+    // not compete for issue slots
+    const int cw = 0;
+    // All 64 lanes stay enabled (lane l redoes channel l mod nvalid): measured on MI355X
+    // (tools/ubench/exec_mask.hip), VALU instructions of a wave with 16 or fewer active lanes
+    // take 3-4x longer than with 32 or more.
+    if (wv == cw)
+      agc_chain(smem + kLdsTabFloats + (nvalid == 4 ? (lane & 3) : lane % nvalid) * kLdsFloatsPerWave, cf0, lane STAMP_ARGS);
+    STAMP(21);  // AGC: the serial chain (chain wave only)
     __syncthreads();
+    STAMP(22);  // AGC: barrier 2 (= waiting for the chain, for the other waves)
   } else {
     wave_sync();
-    agc_chain(lds, cf0);
+    agc_chain(lds, cf0, lane STAMP_ARGS);
     wave_sync();
   }
   {
@@ -617,6 +769,7 @@ __device__ __forceinline__ void agc_apply(const cf (&v)[8], float4 agst, float *
   if (lane < 50) *reinterpret_cast<float4 *>(st_ag + 4 * lane) = lds4(lds + kAgZ + 512 + 4 * lane);
   else if (lane < 52) *reinterpret_cast<float4 *>(st_ag + kAgcHistFloats + 4 * (lane - 50)) = lds4(lds + kAgS + 4 * (lane - 50));
   wave_sync();
+  STAMP(23);  // AGC: gain from volts, scaling, record store
 }
 
 constexpr int kModeSsb = 0, kModeAm = 1, kModeNfm = 2;  // kernel template MODE
@@ -691,6 +844,11 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
 #ifdef T41RX_STAMP
   unsigned long long stamp_acc = 0, stamp_last;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
+  {
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    if (lane == 27) stamp_acc = hwid;  // placement of this wave (WAVE_ID, SIMD_ID, CU_ID, SE_ID ...)
+  }
 #endif
   for (int f = 0; f < a.nframes; ++f) {
     const size_t fbase = ((size_t)(T41RX_ABLATE == 9 ? (ch & 15) : ch) * a.nframes + f) * L;
@@ -1054,7 +1212,7 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
       cf og[4];
       if (AGC) {
         const int left = a.nchan - 4 * (int)blockIdx.x;
-        agc_apply(v, agst, lds, smem, st + st_agc(kStateN), cf0, lane, wv, left < 4 ? left : 4, og);
+        agc_apply(v, agst, lds, smem, st + st_agc(kStateN), cf0, lane, wv, left < 4 ? left : 4, og STAMP_ARGS);
       }
       if (MODE != kModeAm) {
   #pragma unroll

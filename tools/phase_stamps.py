@@ -1,5 +1,5 @@
 """Per-phase cycle shares of the RX kernel from the -DT41RX_STAMP diagnostic build (GPU box).
-usage: T41RX_LIB=.../libt41rx_stamp.so python tools/phase_stamps.py [nchan]"""
+usage: T41RX_LIB=.../libt41rx_stamp.so python tools/phase_stamps.py [nchan] [AGCMode]"""
 import os
 import sys
 
@@ -15,13 +15,17 @@ NAMES = ["wait loads + gain", "DC high-pass", "NCO + mix", "LDS stage + /4 FIR",
          "x2 interpolator", "x4 interp + transpose writes", "transposed reads + stores",
          "first sub-block: wait loads", "prologue d: uniformise state + DC prepass",
          "prologue a: issue loads + SMEM gains", "prologue b: table staging + barrier (first vmcnt wait)",
-         "prologue c: delay lines -> LDS"]
+         "prologue c: delay lines -> LDS",
+         "AGC: magnitudes + look-ahead max", "AGC: barrier 1", "AGC: serial chain (chain wave)",
+         "AGC: barrier 2 (others wait for the chain)", "AGC: gain, scaling, record store",
+         "AGC chain: straight-line blocks", "AGC chain: slow blocks", "AGC chain: NUMBER of slow blocks (not cycles)"]
 
 
 def main():
     nch = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     L, D = 2048, 256
-    rx = T.RxChain(nch, T.default_params(), NCOFreq=np.full(nch, 5000, np.int32))
+    agc = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    rx = T.RxChain(nch, T.default_params(AGCMode=agc), NCOFreq=np.full(nch, 5000, np.int32))
     g = torch.Generator(device="cuda").manual_seed(0)
     I = 0.2 * torch.randn(nch, L, generator=g, device="cuda")
     Q = 0.2 * torch.randn(nch, L, generator=g, device="cuda")
@@ -31,10 +35,29 @@ def main():
         rx.ProcessIQData(I, Q)
     torch.cuda.synchronize()
     st = buf[nch * D:].view(torch.int64).view(nch, 64).cpu().numpy().astype(np.float64)
-    tot = st[:, :19].sum(axis=1)
+    tot = st[:, :len(NAMES)].sum(axis=1)
     print("channels %d: mean wave cycles %.0f (min %.0f max %.0f)" % (nch, tot.mean(), tot.min(), tot.max()))
     for p, name in enumerate(NAMES):
         print("  %2d %-30s %8.0f cycles  %5.1f %%" % (p, name, st[:, p].mean(), 100 * st[:, p].mean() / tot.mean()))
+
+
+    hw = st[:, 27].astype(np.int64)
+    if hw.any():  # HW_ID: WAVE_ID [3:0], SIMD_ID [5:4], PIPE [7:6], CU_ID [11:8], SH [12], SE [15:13] (gfx9 layout)
+        wave, simd, cu, se = hw & 15, (hw >> 4) & 3, (hw >> 8) & 15, (hw >> 13) & 7
+        xcc = (hw >> 16) & 0xffff
+        print("placement of the first 32 waves (channel: simd/wave_id/cu/se/hi16):")
+        print("  " + " ".join("%d:%d/%d/%d/%d/%x" % (c, simd[c], wave[c], cu[c], se[c], xcc[c]) for c in range(32)))
+        for wg in (0, 1, 256, 257, 512):
+            c = 4 * wg
+            if c + 3 < nch:
+                print("  workgroup %4d: simd of waves 0..3 = %s, cu %s, se %s, hi16 %s" % (wg, simd[c:c + 4], cu[c:c + 4], se[c:c + 4], xcc[c:c+4]))
+        key = (hw >> 8)  # everything above simd/wave = the CU identity
+        from collections import Counter
+        per_cu = Counter(key.tolist())
+        print("  distinct CU ids %d, waves per CU id: min %d max %d" % (len(per_cu), min(per_cu.values()), max(per_cu.values())))
+        # chain waves (wave 0 of each workgroup): how many share a (cu, simd)?
+        k0 = Counter(((hw[0::4] >> 8) * 4 + simd[0::4]).tolist())
+        print("  wave 0 of every workgroup: (cu, simd) slots used %d, max sharing %d" % (len(k0), max(k0.values())))
 
 
 if __name__ == "__main__":

@@ -61,6 +61,12 @@ __device__ __forceinline__ void wave_sync() {
 #define T41RX_ABLATE 0
 #endif
 #define T41RX_CUT(n) (T41RX_ABLATE >= (n) && T41RX_ABLATE <= 8)
+// Issue priority falls as a wave advances through its frame (3: loads, mixer, decimators; 2:
+// FFTs and demodulator; 0: interpolators and stores), so the waves sharing a SIMD progress evenly
+// instead of oldest-first, which left each SIMD with one or two latency-bound waves for the last
+// third of the launch (per-wave end times from the -DT41RX_STAMP build: 24 .. 35 us within every
+// CU).  Measured: 33.8 -> 31.6 us; eight other schedules tried, rising priorities lose 0.2 us.
+#define PRIO(n) __builtin_amdgcn_s_setprio(n)
 
 // Diagnostic build only (-DT41RX_STAMP): s_memtime stamps at phase boundaries; lane p of each wave
 // accumulates the cycles of phase p and writes them behind the demod debug tap at the end.
@@ -847,10 +853,16 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
   {
     unsigned hwid;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-    if (lane == 27) stamp_acc = hwid;  // placement of this wave (WAVE_ID, SIMD_ID, CU_ID, SE_ID ...)
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    if (lane == 27) stamp_acc = hwid | ((unsigned long long)(xcc & 0xf) << 32);  // placement of this wave
+    unsigned long long rt;                // constant-rate counter (100 MHz): start / end of the wave
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt)::"memory");
+    if (lane == 28) stamp_acc = rt;
   }
 #endif
   for (int f = 0; f < a.nframes; ++f) {
+    PRIO(3);
     const size_t fbase = ((size_t)(T41RX_ABLATE == 9 ? (ch & 15) : ch) * a.nframes + f) * L;
     const float *__restrict__ gI = a.I + fbase;
     const float *__restrict__ gQ = a.Q + fbase;
@@ -1069,6 +1081,7 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
           }
         }  // h
         STAMP(4);  // history roll
+        if (rd == 1) PRIO(2);
       // ---- decimate by 2 (46 taps) over the 256 new /4 samples: m = 2*lane, 2*lane+1
         wave_sync();
         // y[m] = sum_i c[i] * state[2m + i]; state[i] = buf[i + 3]
@@ -1367,6 +1380,7 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
     }
     wave_sync();
     STAMP(10);  // demod + x2 staging
+    PRIO(0);
     f2 u1[4];  // outputs (2n, 2n+1) of input n = 4 lane + u
     {
       float w[28];
@@ -1451,6 +1465,11 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
   }  // frames
 #ifdef T41RX_STAMP
   // stamps go behind the demod tap's data: dbg_demod must be [nchan*nframes*256 floats | nchan*64 uint64]
+  {
+    unsigned long long rt;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt)::"memory");
+    if (lane == 29) stamp_acc = rt;
+  }
   if (a.dbg_demod)
     reinterpret_cast<unsigned long long *>(a.dbg_demod + (size_t)a.nchan * a.nframes * D)[(size_t)ch * 64 + lane] = stamp_acc;
 #endif

@@ -41,7 +41,29 @@ def main():
         print("  %2d %-30s %8.0f cycles  %5.1f %%" % (p, name, st[:, p].mean(), 100 * st[:, p].mean() / tot.mean()))
 
 
+    t0, t1 = st[:, 28], st[:, 29]  # s_memrealtime (100 MHz) at wave start / end
+    if t0.any():
+        base = t0.min()
+        q = lambda x: " ".join("%.2f" % v for v in np.percentile((x - base) / 100.0, [0, 10, 50, 90, 100]))
+        print("wave start  [us after the first wave, percentiles 0 10 50 90 100]: " + q(t0))
+        print("wave end    [us after the first wave, percentiles 0 10 50 90 100]: " + q(t1))
+        print("wave life   [us, percentiles]: " + " ".join("%.2f" % v for v in np.percentile((t1 - t0) / 100.0, [0, 10, 50, 90, 100])))
     hw = st[:, 27].astype(np.int64)
+    if hw.any() and t0.any():
+        xcc = (hw >> 32) & 15
+        cuid = ((hw >> 8) & 0xff) | (xcc << 8)  # CU_ID, SH, SE + XCC
+        ids = np.unique(cuid)
+        ends = np.array([(t1[cuid == i].max() - base) / 100.0 for i in ids])
+        firsts = np.array([(t1[cuid == i].min() - base) / 100.0 for i in ids])
+        nw = np.array([(cuid == i).sum() for i in ids])
+        print("CUs seen: %d (waves per CU min %d max %d)" % (len(ids), nw.min(), nw.max()))
+        print("per-CU LAST wave end [us]: percentiles 0 10 50 90 100: " + " ".join("%.2f" % v for v in np.percentile(ends, [0, 10, 50, 90, 100])))
+        print("per-CU FIRST wave end [us]: percentiles 0 10 50 90 100: " + " ".join("%.2f" % v for v in np.percentile(firsts, [0, 10, 50, 90, 100])))
+        for x in range(8):
+            m = xcc[np.searchsorted(ids, ids)] if False else None
+        for x in np.unique(xcc):
+            sel = (ids >> 8) == x
+            print("  XCC %d: %3d CUs, last-wave end mean %.2f max %.2f us" % (x, sel.sum(), ends[sel].mean(), ends[sel].max()))
     if hw.any():  # HW_ID: WAVE_ID [3:0], SIMD_ID [5:4], PIPE [7:6], CU_ID [11:8], SH [12], SE [15:13] (gfx9 layout)
         wave, simd, cu, se = hw & 15, (hw >> 4) & 3, (hw >> 8) & 15, (hw >> 13) & 7
         xcc = (hw >> 16) & 0xffff

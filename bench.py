@@ -46,6 +46,9 @@ WORKLOADS = {
     "ssb_agc": dict(batch=4096, fft=512, kw=dict(mode=0, FLoCut=200, FHiCut=3000, AGCMode=1),
                     name="configs[1] with the firmware's default AGCMode = 1 (look-ahead AGC, DSP_Fn.cpp:504-631) instead of "
                          "the fixed gain: 4096 channels x 2048 samples per step (SURVEY 8f rank 1)"),
+    "ssb_q15": dict(batch=4096, fft=512, kw=dict(mode=0, FLoCut=200, FHiCut=3000), q15=True,
+                    name="configs[1] on the firmware's own sample format either side (q15 record-queue blocks in, "
+                         "arm_float_to_q15 out; Process.cpp:102-111, 936): 6 B per input complex sample (SURVEY 8f rank 3)"),
     "fft4096": dict(batch=1024, fft=4096, kw=dict(mode=0, FLoCut=400, FHiCut=600),
                     name="configs[3]: PSK31-like narrow USB filter, 4096-pt fast-conv (synthetic generalisation), "
                          "1024 channels x 16384 samples per step"),
@@ -175,9 +178,19 @@ def main():
     Is, Qs = synth_ring(N_CHANNELS, nco, RING, dev, seed=0x5441315F + rank, mode=params.mode)
     outs = [torch.empty(N_CHANNELS, FRAME_LEN, device=dev, dtype=torch.float32) for _ in range(RING)]
 
+    q15 = bool(wl.get("q15"))
+    bytes_per_sample = 6.0 if q15 else BYTES_PER_SAMPLE  # 2 x int16 in + int16 out
+    if q15:  # what the codec would deliver for these waveforms
+        Is = [(x * 32768.0).round_().clamp_(-32768, 32767).to(torch.int16) for x in Is]
+        Qs = [(x * 32768.0).round_().clamp_(-32768, 32767).to(torch.int16) for x in Qs]
+        outs = [torch.empty(N_CHANNELS, FRAME_LEN, device=dev, dtype=torch.int16) for _ in range(RING)]
+
     def step(k):
         r = k % RING
-        rx.ProcessIQData(Is[r], Qs[r], out=outs[r])
+        if q15:
+            rx.ProcessIQData_q15(Qs[r], Is[r], out=outs[r])  # L queue carries Q, R queue carries I
+        else:
+            rx.ProcessIQData(Is[r], Qs[r], out=outs[r])
 
     for k in range(args.warmup):
         step(k)
@@ -203,12 +216,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
 
-    if not os.environ.get("T41RX_BENCH_NOCHECK") and not torch.isfinite(outs[(args.warmup + args.steps - 1) % RING]).all():
+    if not q15 and not os.environ.get("T41RX_BENCH_NOCHECK") and not torch.isfinite(outs[(args.warmup + args.steps - 1) % RING]).all():
         raise SystemExit("non-finite audio output")
 
     samples_per_step = N_CHANNELS * FRAME_LEN
     value = world * samples_per_step * args.steps / wall / 1e6
-    achieved = BYTES_PER_SAMPLE * samples_per_step / (kernel_ms * 1e-3) / 1e9
+    achieved = bytes_per_sample * samples_per_step / (kernel_ms * 1e-3) / 1e9
     line = {
         "metric": "MSamples/s I/Q through full RX chain, batch=4096; achieved HBM GB/s vs roofline",
         "value": round(value, 1),
@@ -220,7 +233,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f32" if not q15 else "f32 (q15 samples in and out)",
         "data": "synthetic",
         "config": {
             "workload": wl["name"],
@@ -233,10 +246,10 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": load_traffic(),
+            "traffic": load_traffic() if args.workload == "ssb" else None,
             "kernel": "rx512_kernel" if FFT_LENGTH == 512 else "rx512_kernel<front> + fastconv4096_kernel + rx512_kernel<back>",
             "kernel_ms": round(kernel_ms, 5),
-            "algorithmic_bytes_per_launch": int(BYTES_PER_SAMPLE * samples_per_step),
+            "algorithmic_bytes_per_launch": int(bytes_per_sample * samples_per_step),
         },
     }
     if rank == 0:

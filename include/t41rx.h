@@ -140,6 +140,19 @@ int t41rx_process_device(t41rx_ctx *ctx, const float *dI, const float *dQ, float
 int t41rx_process_host(t41rx_ctx *ctx, const float *I, const float *Q, float *audio,
                        int n_frames);
 
+/* The same call on the firmware's own sample format either side of the path: q15 samples as the
+ * AudioRecordQueues deliver them and as the AudioPlayQueue takes them.  Restates
+ *   arm_q15_to_float(Q_in_R.readBuffer(), &float_buffer_L[...]); arm_q15_to_float(Q_in_L.readBuffer(),
+ *   &float_buffer_R[...])                     Process.cpp:107-108 (note the swap: I comes from the R queue)
+ *   arm_float_to_q15(float_buffer_L, q15_buffer_LTemp, 2048); Q_out_L.play(...)    Process.cpp:936-937
+ * with CMSIS-DSP's conversions (x / 32768; truncating, saturating (q15_t)__SSAT((q31_t)(x * 32768), 16)).
+ * Layout [n_channels][n_frames*frame_len] int16, the 16 blocks of 128 of a frame back to back.
+ * fft_length 512 only; not available while debug taps are set. */
+int t41rx_process_device_q15(t41rx_ctx *ctx, const int16_t *dQ_in_L, const int16_t *dQ_in_R,
+                             int16_t *dQ_out_L, int n_frames, void *hip_stream);
+int t41rx_process_host_q15(t41rx_ctx *ctx, const int16_t *Q_in_L, const int16_t *Q_in_R,
+                           int16_t *Q_out_L, int n_frames);
+
 /* ---- checkpoint of the streaming state (the reference never persists it) ---- */
 size_t t41rx_state_bytes(const t41rx_ctx *ctx);
 int    t41rx_get_state(t41rx_ctx *ctx, void *host_buf, size_t bytes);

@@ -1099,3 +1099,62 @@ int t41o_process_batch(t41o_channel **chs, int nchan, int nframes, const t41o_pa
   }
   return rc;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * The q15 boundary of ProcessIQData(): Process.cpp:102-111 (in) and :936-937 (out)
+ * ---------------------------------------------------------------------------------------- */
+
+/* arm_q15_to_float (CMSIS-DSP, scalar): pDst[i] = (float32_t)pSrc[i] / 32768.0f */
+void t41o_q15_to_float(const int16_t *src, float *dst, int n) {
+  for (int i = 0; i < n; i++) dst[i] = ((float)src[i] / 32768.0f);
+}
+
+/* arm_float_to_q15 (CMSIS-DSP, scalar, ARM_MATH_ROUNDING not defined -- the library default):
+ * pDst[i] = (q15_t)__SSAT((q31_t)(pSrc[i] * 32768.0f), 16): truncation toward zero, saturation */
+void t41o_float_to_q15(const float *src, int16_t *dst, int n) {
+  for (int i = 0; i < n; i++) {
+    float in = src[i] * 32768.0f;
+    int32_t v; /* (q31_t)(float): the Cortex-M VCVT saturates out-of-range values */
+    if (in >= 2147483648.0f) v = INT32_MAX;
+    else if (in <= -2147483648.0f) v = INT32_MIN;
+    else v = (int32_t)in;
+    if (v > 32767) v = 32767; /* __SSAT(v, 16) */
+    if (v < -32768) v = -32768;
+    dst[i] = (int16_t)v;
+  }
+}
+
+/* One ProcessIQData() including its sample-format boundary.  Q_in_L / Q_in_R: the N_BLOCKS = 16
+ * blocks of BUFFER_SIZE = 128 q15 samples read from the two record queues, back to back
+ * (generalised to frame_len samples).  Process.cpp:107-108 converts the R queue into float_buffer_L
+ * (I) and the L queue into float_buffer_R (Q); :936-937 plays arm_float_to_q15(float_buffer_L). */
+int t41o_process_frame_q15(t41o_channel *ch, const t41o_params *p, const t41o_coeffs *c,
+                           long NCOFreq, const int16_t *Q_in_L, const int16_t *Q_in_R,
+                           int16_t *Q_out_L) {
+  const int L = ch->L;
+  float *I = (float *)malloc(sizeof(float) * (size_t)L * 3);
+  float *Q = I + L, *audio = Q + L;
+  const int BUFFER_SIZE = 128; /* SDT.h:70 */
+  for (int i = 0; i < L / BUFFER_SIZE; i++) {
+    t41o_q15_to_float(Q_in_R + BUFFER_SIZE * i, &I[BUFFER_SIZE * i], BUFFER_SIZE);
+    t41o_q15_to_float(Q_in_L + BUFFER_SIZE * i, &Q[BUFFER_SIZE * i], BUFFER_SIZE);
+  }
+  int rc = t41o_process_frame(ch, p, c, NCOFreq, I, Q, audio);
+  if (rc == 0) t41o_float_to_q15(audio, Q_out_L, L);
+  free(I);
+  return rc;
+}
+
+int t41o_process_batch_q15(t41o_channel **chs, int nchan, int nframes, const t41o_params *p,
+                           const t41o_coeffs *c, const int32_t *NCOFreq, const int16_t *Q_in_L,
+                           const int16_t *Q_in_R, int16_t *Q_out_L) {
+  for (int ch = 0; ch < nchan; ch++) {
+    const int L = chs[ch]->L;
+    for (int f = 0; f < nframes; f++) {
+      const size_t o = ((size_t)ch * (size_t)nframes + (size_t)f) * (size_t)L;
+      int rc = t41o_process_frame_q15(chs[ch], p, c, NCOFreq[ch], Q_in_L + o, Q_in_R + o, Q_out_L + o);
+      if (rc) return rc;
+    }
+  }
+  return 0;
+}

@@ -128,6 +128,18 @@ int t41o_process_batch(t41o_channel **chs, int nchan, int nframes, const t41o_pa
                        const t41o_coeffs *c, const int32_t *NCOFreq, const float *I,
                        const float *Q, float *audio, int nthreads);
 
+/* The q15 boundary of ProcessIQData() (Process.cpp:102-111, 936-937): arm_q15_to_float /
+ * arm_float_to_q15 restated, and the block function on the record/play queues' sample format
+ * (I is read from the R queue, Q from the L queue).  Layouts as above with int16 samples. */
+void t41o_q15_to_float(const int16_t *src, float *dst, int n);
+void t41o_float_to_q15(const float *src, int16_t *dst, int n);
+int t41o_process_frame_q15(t41o_channel *ch, const t41o_params *p, const t41o_coeffs *c,
+                           long NCOFreq, const int16_t *Q_in_L, const int16_t *Q_in_R,
+                           int16_t *Q_out_L);
+int t41o_process_batch_q15(t41o_channel **chs, int nchan, int nframes, const t41o_params *p,
+                           const t41o_coeffs *c, const int32_t *NCOFreq, const int16_t *Q_in_L,
+                           const int16_t *Q_in_R, int16_t *Q_out_L);
+
 /* debugging taps for stage-level parity tests: copies of intermediate buffers of the
  * last processed frame (lengths in floats); returns number of floats written */
 enum {

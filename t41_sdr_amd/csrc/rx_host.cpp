@@ -385,8 +385,30 @@ int t41rx_reset(t41rx_ctx *ctx) {
 int t41rx_n_channels(const t41rx_ctx *ctx) { return ctx ? ctx->nchan : T41RX_ERR_ARG; }
 int t41rx_frame_len(const t41rx_ctx *ctx) { return ctx ? 4 * ctx->params.fft_length : T41RX_ERR_ARG; }
 
+namespace {
+int process_device_impl(t41rx_ctx *ctx, const float *dI, const float *dQ, float *dAudio, int n_frames,
+                        void *hip_stream, bool q15);
+}
+
 int t41rx_process_device(t41rx_ctx *ctx, const float *dI, const float *dQ, float *dAudio, int n_frames,
                          void *hip_stream) {
+  return process_device_impl(ctx, dI, dQ, dAudio, n_frames, hip_stream, false);
+}
+
+// float_buffer_L (= I) is filled from the R queue and float_buffer_R (= Q) from the L queue
+// (Process.cpp:107-108)
+int t41rx_process_device_q15(t41rx_ctx *ctx, const int16_t *dQ_in_L, const int16_t *dQ_in_R, int16_t *dQ_out_L,
+                             int n_frames, void *hip_stream) {
+  if (ctx && ctx->params.fft_length != 512) return fail(T41RX_ERR_UNSUPPORTED, "the q15 entry points are built for fft_length 512");
+  if (ctx && (ctx->dbg_nco || ctx->dbg_dec || ctx->dbg_demod))
+    return fail(T41RX_ERR_UNSUPPORTED, "debug taps are not available on the q15 entry points");
+  return process_device_impl(ctx, reinterpret_cast<const float *>(dQ_in_R), reinterpret_cast<const float *>(dQ_in_L),
+                             reinterpret_cast<float *>(dQ_out_L), n_frames, hip_stream, true);
+}
+
+namespace {
+int process_device_impl(t41rx_ctx *ctx, const float *dI, const float *dQ, float *dAudio, int n_frames,
+                        void *hip_stream, bool q15) {
   if (!ctx || !dI || !dQ || !dAudio) return fail(T41RX_ERR_ARG, "null argument");
   if (n_frames <= 0) return fail(T41RX_ERR_ARG, "n_frames must be > 0");
   if ((reinterpret_cast<uintptr_t>(dI) | reinterpret_cast<uintptr_t>(dQ) | reinterpret_cast<uintptr_t>(dAudio)) & 15u)
@@ -425,6 +447,7 @@ int t41rx_process_device(t41rx_ctx *ctx, const float *dI, const float *dQ, float
     const float gi = iq_on ? sc[kScBandGain] * sc[kScNegIqAmp] : sc[kScBandGain];
     a.plain = ((gi == 1.0f || (iq_on && gi == -1.0f)) && sc[kScBandGain] == 1.0f && (!iq_on || sc[kScIqPhase] == 0.0f)) ? 1 : 0;
   }
+  a.q15 = q15 ? 1 : 0;
   a.agc = ctx->params.AGCMode != 0 ? 1 : 0;
   if (a.agc && (int)blob_view(ctx->blob.data()).agc[kAgcAttackBuffsize] != kAgcDelay)
     return fail(T41RX_ERR_STATE, "coefficient blob carries an AGC look-ahead the kernel is not built for");
@@ -436,22 +459,50 @@ int t41rx_process_device(t41rx_ctx *ctx, const float *dI, const float *dQ, float
   return T41RX_OK;
 }
 
+// staging buffers of the host-pointer entry points, sized in bytes per array
+int ensure_staging(t41rx_ctx *ctx, size_t bytes) {
+  if (bytes <= ctx->staging_floats * sizeof(float)) return T41RX_OK;
+  (void)hipFree(ctx->d_in_i);
+  (void)hipFree(ctx->d_in_q);
+  (void)hipFree(ctx->d_out);
+  ctx->d_in_i = ctx->d_in_q = ctx->d_out = nullptr;
+  ctx->staging_floats = 0;
+  const size_t nfl = (bytes + sizeof(float) - 1) / sizeof(float);
+  HIP_TRY(hipMalloc((void **)&ctx->d_in_i, nfl * sizeof(float)));
+  HIP_TRY(hipMalloc((void **)&ctx->d_in_q, nfl * sizeof(float)));
+  HIP_TRY(hipMalloc((void **)&ctx->d_out, nfl * sizeof(float)));
+  ctx->staging_floats = nfl;
+  return T41RX_OK;
+}
+}  // namespace
+
+int t41rx_process_host_q15(t41rx_ctx *ctx, const int16_t *Q_in_L, const int16_t *Q_in_R, int16_t *Q_out_L, int n_frames) {
+  if (!ctx || !Q_in_L || !Q_in_R || !Q_out_L) return fail(T41RX_ERR_ARG, "null argument");
+  if (n_frames <= 0) return fail(T41RX_ERR_ARG, "n_frames must be > 0");
+  DeviceGuard g(ctx->device);
+  if (!g.ok) return fail(T41RX_ERR_HIP, "hipSetDevice failed");
+  const size_t bytes = (size_t)ctx->nchan * (size_t)n_frames * (size_t)(4 * ctx->params.fft_length) * sizeof(int16_t);
+  int rc = ensure_staging(ctx, bytes);
+  if (rc != T41RX_OK) return rc;
+  HIP_TRY(hipMemcpy(ctx->d_in_i, Q_in_L, bytes, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(ctx->d_in_q, Q_in_R, bytes, hipMemcpyHostToDevice));
+  rc = t41rx_process_device_q15(ctx, reinterpret_cast<const int16_t *>(ctx->d_in_i), reinterpret_cast<const int16_t *>(ctx->d_in_q),
+                                reinterpret_cast<int16_t *>(ctx->d_out), n_frames, nullptr);
+  if (rc != T41RX_OK) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(Q_out_L, ctx->d_out, bytes, hipMemcpyDeviceToHost));
+  return T41RX_OK;
+}
+
 int t41rx_process_host(t41rx_ctx *ctx, const float *I, const float *Q, float *audio, int n_frames) {
   if (!ctx || !I || !Q || !audio) return fail(T41RX_ERR_ARG, "null argument");
   if (n_frames <= 0) return fail(T41RX_ERR_ARG, "n_frames must be > 0");
   DeviceGuard g(ctx->device);
   if (!g.ok) return fail(T41RX_ERR_HIP, "hipSetDevice failed");
   const size_t nfl = (size_t)ctx->nchan * (size_t)n_frames * (size_t)(4 * ctx->params.fft_length);
-  if (nfl > ctx->staging_floats) {
-    (void)hipFree(ctx->d_in_i);
-    (void)hipFree(ctx->d_in_q);
-    (void)hipFree(ctx->d_out);
-    ctx->d_in_i = ctx->d_in_q = ctx->d_out = nullptr;
-    ctx->staging_floats = 0;
-    HIP_TRY(hipMalloc((void **)&ctx->d_in_i, nfl * sizeof(float)));
-    HIP_TRY(hipMalloc((void **)&ctx->d_in_q, nfl * sizeof(float)));
-    HIP_TRY(hipMalloc((void **)&ctx->d_out, nfl * sizeof(float)));
-    ctx->staging_floats = nfl;
+  {
+    const int rc0 = ensure_staging(ctx, nfl * sizeof(float));
+    if (rc0 != T41RX_OK) return rc0;
   }
   HIP_TRY(hipMemcpy(ctx->d_in_i, I, nfl * sizeof(float), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(ctx->d_in_q, Q, nfl * sizeof(float), hipMemcpyHostToDevice));

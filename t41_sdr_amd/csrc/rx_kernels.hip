@@ -351,6 +351,18 @@ __device__ __forceinline__ void stg_stream(float *p, float4 v) {
   __builtin_nontemporal_store(f4n{v.x, v.y, v.z, v.w}, reinterpret_cast<f4n *>(p));
 }
 
+// the two q15 samples packed in one 32-bit word, as floats (exact)
+__device__ __forceinline__ float q15_lo(float w) { return (float)(short)(__float_as_uint(w) & 0xffffu); }
+__device__ __forceinline__ float q15_hi(float w) { return (float)(__float_as_int(w) >> 16); }
+// arm_float_to_q15 (CMSIS-DSP scalar path without ARM_MATH_ROUNDING): (q15_t)__SSAT((q31_t)(x * 32768.0f), 16);
+// two of them packed, first sample in the low half
+__device__ __forceinline__ unsigned q15_pack2(float x0, float x1) {
+  int a = (int)(x0 * 32768.0f), b = (int)(x1 * 32768.0f);  // v_cvt_i32_f32: toward zero, saturating
+  a = a < -32768 ? -32768 : (a > 32767 ? 32767 : a);
+  b = b < -32768 ? -32768 : (b > 32767 ? 32767 : b);
+  return ((unsigned)a & 0xffffu) | ((unsigned)b << 16);
+}
+
 typedef float f4v __attribute__((ext_vector_type(4)));
 typedef float f8v __attribute__((ext_vector_type(8)));
 typedef float f16v __attribute__((ext_vector_type(16)));
@@ -793,7 +805,12 @@ constexpr int kModeSsb = 0, kModeAm = 1, kModeNfm = 2;  // kernel template MODE
 // multiply of I, which is exact because the DC high-pass in between is linear and negation is exact
 // (the I chain's carry is negated with it).
 // AGC: AGCMode != 0 (see agc_apply); the demodulator then works on lane-contiguous samples.
-template <int MODE, bool DEBUG, int PART, bool PLAIN, bool AGC = false>
+// WQ15: the firmware's own sample format either side of the path -- q15 blocks from the
+// AudioRecordQueues in (arm_q15_to_float, Process.cpp:102-111) and arm_float_to_q15 out
+// (Process.cpp:936): a.I / a.Q / a.out then point at int16 samples, same [channel][frame*2048]
+// layout.  The conversions are exact (x / 32768 folds into the RF-gain factor, a power of two)
+// resp. CMSIS' truncating, saturating float -> q15.
+template <int MODE, bool DEBUG, int PART, bool PLAIN, bool AGC = false, bool WQ15 = false>
 __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int L = 2048, D = 256, N = 512;
@@ -864,9 +881,10 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
   for (int f = 0; f < a.nframes; ++f) {
     PRIO(3);
     const size_t fbase = ((size_t)(T41RX_ABLATE == 9 ? (ch & 15) : ch) * a.nframes + f) * L;
-    const float *__restrict__ gI = a.I + fbase;
-    const float *__restrict__ gQ = a.Q + fbase;
-    float *__restrict__ gO = a.out + fbase;
+    // (WQ15: two samples per float slot, so sample offsets halve)
+    const float *__restrict__ gI = a.I + (WQ15 ? fbase / 2 : fbase);
+    const float *__restrict__ gQ = a.Q + (WQ15 ? fbase / 2 : fbase);
+    float *__restrict__ gO = a.out + (WQ15 ? fbase / 2 : fbase);
 
     constexpr bool CONTIG = (MODE == kModeAm) || AGC;  // aud[j] = sample 4 lane + j instead of lane + 64 j
     float aud[4];                            // 4 demodulated samples @24 kS/s
@@ -887,11 +905,19 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
       // order): sub-block 0, the I tail for Q's DC-block start state, the delay lines, then
       // sub-block 1.  Input prefetch runs TWO sub-blocks ahead (two register sets, even / odd).
       float4 pI0[2], pI1[2], pQ0[2], pQ1[2];
-      pI0[0] = ldg_stream(gI + 8 * lane);
-      pI1[0] = ldg_stream(gI + 8 * lane + 4);
-      pQ0[0] = ldg_stream(gQ + 8 * lane);
-      pQ1[0] = ldg_stream(gQ + 8 * lane + 4);
-      const float4 tailI = *reinterpret_cast<const float4 *>(gI + (L - 256) + 4 * lane);
+      float4 tailI;
+      if (!WQ15) {
+        pI0[0] = ldg_stream(gI + 8 * lane);
+        pI1[0] = ldg_stream(gI + 8 * lane + 4);
+        pQ0[0] = ldg_stream(gQ + 8 * lane);
+        pQ1[0] = ldg_stream(gQ + 8 * lane + 4);
+        tailI = *reinterpret_cast<const float4 *>(gI + (L - 256) + 4 * lane);
+      } else {  // 8 samples = 16 bytes per lane and array
+        pI0[0] = ldg_stream(gI + 4 * lane);
+        pQ0[0] = ldg_stream(gQ + 4 * lane);
+        const float2 t = *reinterpret_cast<const float2 *>(gI + (L - 256) / 2 + 2 * lane);
+        tailI = make_float4(q15_lo(t.x), q15_hi(t.x), q15_lo(t.y), q15_hi(t.y));
+      }
       float4 h1 = make_float4(0, 0, 0, 0), h2 = make_float4(0, 0, 0, 0);
       if (lane < 14) h1 = *reinterpret_cast<const float4 *>(st + kStDec1 + 4 * lane);
       if (lane < 24) h2 = *reinterpret_cast<const float4 *>(st + kStDec2 + 4 * lane);
@@ -902,6 +928,7 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
       {
         const CoefPtr c = fresh_coef(cf0);
         g_rf = c->sc[kScRfGain];
+        if (WQ15) g_rf *= 1.0f / 32768.0f;  // arm_q15_to_float
         // PLAIN: sign of the I path (-1 when the IQ amplitude correction applies, Process.cpp:165-173)
         g_rf_i = (PLAIN && c->sc[kScIqCorrOn] != 0.0f) ? -g_rf : g_rf;
         if (!PLAIN) {
@@ -916,10 +943,15 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
       STAMP(16);  // prologue a: issue + scalar (SMEM) gains
       if (f == 0) stage_tables();
       STAMP(17);  // prologue b: table staging + workgroup barrier (first vmcnt wait)
-      pI0[1] = ldg_stream(gI + 512 + 8 * lane);
-      pI1[1] = ldg_stream(gI + 512 + 8 * lane + 4);
-      pQ0[1] = ldg_stream(gQ + 512 + 8 * lane);
-      pQ1[1] = ldg_stream(gQ + 512 + 8 * lane + 4);
+      if (!WQ15) {
+        pI0[1] = ldg_stream(gI + 512 + 8 * lane);
+        pI1[1] = ldg_stream(gI + 512 + 8 * lane + 4);
+        pQ0[1] = ldg_stream(gQ + 512 + 8 * lane);
+        pQ1[1] = ldg_stream(gQ + 512 + 8 * lane + 4);
+      } else {
+        pI0[1] = ldg_stream(gI + 256 + 4 * lane);
+        pQ0[1] = ldg_stream(gQ + 256 + 4 * lane);
+      }
 
       // ---- delay lines -> LDS (every frame is self-contained: load state, run, store state)
       wave_sync();
@@ -958,20 +990,35 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
           const int s = 2 * rd + h;
           // -- RF gain (Process.cpp:117-119); the multiply also interleaves I and Q into pairs
           cf z[8];
-          z[0] = cf{pI0[h].x * g_rf_i, pQ0[h].x * g_rf};
-          z[1] = cf{pI0[h].y * g_rf_i, pQ0[h].y * g_rf};
-          z[2] = cf{pI0[h].z * g_rf_i, pQ0[h].z * g_rf};
-          z[3] = cf{pI0[h].w * g_rf_i, pQ0[h].w * g_rf};
-          z[4] = cf{pI1[h].x * g_rf_i, pQ1[h].x * g_rf};
-          z[5] = cf{pI1[h].y * g_rf_i, pQ1[h].y * g_rf};
-          z[6] = cf{pI1[h].z * g_rf_i, pQ1[h].z * g_rf};
-          z[7] = cf{pI1[h].w * g_rf_i, pQ1[h].w * g_rf};
+          if (!WQ15) {
+            z[0] = cf{pI0[h].x * g_rf_i, pQ0[h].x * g_rf};
+            z[1] = cf{pI0[h].y * g_rf_i, pQ0[h].y * g_rf};
+            z[2] = cf{pI0[h].z * g_rf_i, pQ0[h].z * g_rf};
+            z[3] = cf{pI0[h].w * g_rf_i, pQ0[h].w * g_rf};
+            z[4] = cf{pI1[h].x * g_rf_i, pQ1[h].x * g_rf};
+            z[5] = cf{pI1[h].y * g_rf_i, pQ1[h].y * g_rf};
+            z[6] = cf{pI1[h].z * g_rf_i, pQ1[h].z * g_rf};
+            z[7] = cf{pI1[h].w * g_rf_i, pQ1[h].w * g_rf};
+          } else {  // arm_q15_to_float (x / 32768, exact) is part of g_rf here
+            const float wi[4] = {pI0[h].x, pI0[h].y, pI0[h].z, pI0[h].w}, wq[4] = {pQ0[h].x, pQ0[h].y, pQ0[h].z, pQ0[h].w};
+  #pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              z[2 * k] = cf{q15_lo(wi[k]) * g_rf_i, q15_lo(wq[k]) * g_rf};
+              z[2 * k + 1] = cf{q15_hi(wi[k]) * g_rf_i, q15_hi(wq[k]) * g_rf};
+            }
+          }
           if (s < 2) {  // refill this register set with the sub-block after next
-            const int o = 512 * (s + 2) + 8 * lane;
-            pI0[h] = ldg_stream(gI + o);
-            pI1[h] = ldg_stream(gI + o + 4);
-            pQ0[h] = ldg_stream(gQ + o);
-            pQ1[h] = ldg_stream(gQ + o + 4);
+            if (!WQ15) {
+              const int o = 512 * (s + 2) + 8 * lane;
+              pI0[h] = ldg_stream(gI + o);
+              pI1[h] = ldg_stream(gI + o + 4);
+              pQ0[h] = ldg_stream(gQ + o);
+              pQ1[h] = ldg_stream(gQ + o + 4);
+            } else {
+              const int o = 256 * (s + 2) + 4 * lane;
+              pI0[h] = ldg_stream(gI + o);
+              pQ0[h] = ldg_stream(gQ + o);
+            }
           } else if (s == 3) {  // last sub-block: prefetch the overlap-save "previous" block instead
             const cf *ov = reinterpret_cast<const cf *>(st + kStOverlap);
   #pragma unroll
@@ -1436,6 +1483,7 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
       // each float4 goes to an XOR-swizzled LDS slot first (slot 8 lane + (u ^ (lane & 7)):
       // conflict-free both for these row writes and for the column reads below) ...
       wave_sync();
+      unsigned qw[2] = {0u, 0u};  // WQ15: the four packed samples of the even u
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         f2 o01 = splat(0.0f), o23 = splat(0.0f);
@@ -1448,17 +1496,36 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
         // ---- volume (Process.cpp:929)
         o01 *= splat(out_scale);
         o23 *= splat(out_scale);
-        *reinterpret_cast<float4 *>(lds + 4 * (8 * lane + (u ^ (lane & 7)))) = make_float4(o01.x, o01.y, o23.x, o23.y);
+        if (!WQ15) {
+          *reinterpret_cast<float4 *>(lds + 4 * (8 * lane + (u ^ (lane & 7)))) = make_float4(o01.x, o01.y, o23.x, o23.y);
+        } else if ((u & 1) == 0) {  // arm_float_to_q15 (Process.cpp:936)
+          qw[0] = q15_pack2(o01.x, o01.y);
+          qw[1] = q15_pack2(o23.x, o23.y);
+        } else {
+          // 8 samples = one 16-byte piece; a lane has 4 of them: slot 4 lane + (piece ^ swizzle)
+          const int piece = u >> 1;
+          *reinterpret_cast<uint4 *>(lds + 4 * (4 * lane + (piece ^ ((lane >> 2) & 3)))) =
+              make_uint4(qw[0], qw[1], q15_pack2(o01.x, o01.y), q15_pack2(o23.x, o23.y));
+        }
       }
       wave_sync();
       STAMP(12);  // x4 interpolator + LDS transpose writes
       // ... and every global store instruction then writes 1 KiB of consecutive addresses:
       // float4 index F = 64 i + lane lives in row F >> 3 = 8 i + (lane >> 3), column lane & 7
+      if (!WQ15) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int row = 8 * i + (lane >> 3);
-        const float4 t = lds4(lds + 4 * (8 * row + ((lane & 7) ^ (row & 7))));
-        stg_stream(gO + 256 * i + 4 * lane, t);
+        for (int i = 0; i < 8; ++i) {
+          const int row = 8 * i + (lane >> 3);
+          const float4 t = lds4(lds + 4 * (8 * row + ((lane & 7) ^ (row & 7))));
+          stg_stream(gO + 256 * i + 4 * lane, t);
+        }
+      } else {  // 4 pieces per row: piece F = 64 i + lane is row F >> 2, column lane & 3
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = 16 * i + (lane >> 2);
+          const float4 t = lds4(lds + 4 * (4 * row + ((lane & 3) ^ ((row >> 2) & 3))));
+          stg_stream(gO + 256 * i + 4 * lane, t);
+        }
       }
     }
     STAMP(13);  // transposed reads + global stores
@@ -1584,7 +1651,17 @@ static hipError_t launch512(const RxArgs &a, hipStream_t s, bool debug) {
   // per CU, so a 4096-channel batch is one full, balanced wave of work on 256 CUs.
   const size_t lds = 40960;
   static_assert((kLdsTabFloats + 4 * kLdsFloatsPerWave) * sizeof(float) <= 40960, "LDS slice too large");
-  if (a.agc) {
+  if (a.q15) {  // the firmware's q15 sample format either side (no debug taps: refused by the host)
+    if (a.agc) {
+      if (a.plain)
+        hipLaunchKernelGGL((rx512_kernel<MODE, false, 0, true, true, true>), dim3(grid), dim3(256), lds, s, a);
+      else
+        hipLaunchKernelGGL((rx512_kernel<MODE, false, 0, false, true, true>), dim3(grid), dim3(256), lds, s, a);
+    } else if (a.plain)
+      hipLaunchKernelGGL((rx512_kernel<MODE, false, 0, true, false, true>), dim3(grid), dim3(256), lds, s, a);
+    else
+      hipLaunchKernelGGL((rx512_kernel<MODE, false, 0, false, false, true>), dim3(grid), dim3(256), lds, s, a);
+  } else if (a.agc) {
     if (debug)
       hipLaunchKernelGGL((rx512_kernel<MODE, true, 0, false, true>), dim3(grid), dim3(256), lds, s, a);
     else if (a.plain)

@@ -40,6 +40,7 @@ struct RxArgs {
   int nframes4k;           // number of 4096-frames (= nframes / 8 for the part kernels)
   int plain;               // 1: unit band/IQ gains and zero IQ phase correction -> specialised kernel
   int agc;                 // 1: AGCMode != 0 (look-ahead AGC, DSP_Fn.cpp:504-631)
+  int q15;                 // 1: I, Q, out point at int16 (q15) samples instead of f32 (Process.cpp:102-111, 936)
 };
 
 // constant table of the 4096-point fast convolution (float2 units):

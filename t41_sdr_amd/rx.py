@@ -134,6 +134,33 @@ class RxChain:
                                              C.c_void_p(stream)))
         return audio
 
+    def ProcessIQData_q15(self, Q_in_L, Q_in_R, out=None):
+        """The same on the firmware's wire format (Process.cpp:102-111, 936-937): int16 (q15) blocks
+        of the L and R record queues in -- I is taken from the R queue, Q from the L queue, as the
+        firmware does -- and the q15 samples handed to Q_out_L.play() out.
+        torch CUDA int16 tensors or numpy int16 arrays, [n_channels, n_frames*frame_len]."""
+        if isinstance(Q_in_L, np.ndarray):
+            a = np.ascontiguousarray(Q_in_L, dtype=np.int16)
+            b = np.ascontiguousarray(Q_in_R, dtype=np.int16)
+            nfr = self._check_shape(a.shape, b.shape)
+            audio = np.empty_like(a) if out is None else out
+            check(self._lib.t41rx_process_host_q15(self._ctx, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p),
+                                                   audio.ctypes.data_as(C.c_void_p), nfr))
+            return audio
+        import torch
+        a, b = Q_in_L, Q_in_R
+        if not (a.is_cuda and b.is_cuda and a.dtype == torch.int16 and b.dtype == torch.int16
+                and a.is_contiguous() and b.is_contiguous()):
+            raise ValueError("Q_in_L/Q_in_R must be contiguous int16 CUDA tensors")
+        if a.device.index != self.device or b.device.index != self.device:
+            raise ValueError("the queues live on another device than this RxChain")
+        nfr = self._check_shape(tuple(a.shape), tuple(b.shape))
+        audio = torch.empty_like(a) if out is None else out
+        stream = torch.cuda.current_stream(a.device).cuda_stream
+        check(self._lib.t41rx_process_device_q15(self._ctx, a.data_ptr(), b.data_ptr(), audio.data_ptr(), nfr,
+                                                 C.c_void_p(stream)))
+        return audio
+
     def set_debug_taps(self, post_nco=None, dec=None, demod=None):
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
         check(self._lib.t41rx_set_debug_taps(self._ctx, ptr(post_nco), ptr(dec), ptr(demod)))

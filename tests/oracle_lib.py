@@ -92,6 +92,12 @@ def lib(native=False):
     L.t41o_process_batch.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.POINTER(Params),
                                      C.POINTER(Coeffs), C.POINTER(C.c_int32), fp, fp, fp, C.c_int]
     L.t41o_process_batch.restype = C.c_int
+    sp = C.POINTER(C.c_int16)
+    L.t41o_q15_to_float.argtypes = [sp, fp, C.c_int]
+    L.t41o_float_to_q15.argtypes = [fp, sp, C.c_int]
+    L.t41o_process_batch_q15.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.POINTER(Params),
+                                         C.POINTER(Coeffs), C.POINTER(C.c_int32), sp, sp, sp]
+    L.t41o_process_batch_q15.restype = C.c_int
     L.t41o_channel_tap.argtypes = [C.c_void_p, C.c_int, fp, C.c_int]
     L.t41o_channel_tap.restype = C.c_int
     if not native:
@@ -167,6 +173,19 @@ class OracleBatch:
                                        fptr(I), fptr(Q), fptr(out), nthreads)
         if rc:
             raise RuntimeError("t41o_process_batch rc=%d" % rc)
+        return out
+
+    def process_q15(self, Q_in_L, Q_in_R):
+        a = np.ascontiguousarray(Q_in_L, dtype=np.int16)
+        b = np.ascontiguousarray(Q_in_R, dtype=np.int16)
+        assert a.shape == b.shape and a.shape[0] == self.nchan and a.shape[1] % self.frame_len == 0
+        out = np.empty_like(a)
+        sp = C.POINTER(C.c_int16)
+        rc = self.L.t41o_process_batch_q15(self.chs, self.nchan, a.shape[1] // self.frame_len, C.byref(self.p),
+                                           C.byref(self.c), self.nco.ctypes.data_as(C.POINTER(C.c_int32)),
+                                           a.ctypes.data_as(sp), b.ctypes.data_as(sp), out.ctypes.data_as(sp))
+        if rc:
+            raise RuntimeError("t41o_process_batch_q15 rc=%d" % rc)
         return out
 
     def tap(self, ch, which, n):

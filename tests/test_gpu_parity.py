@@ -166,6 +166,55 @@ def test_agc_mode_change_and_reset(T):
     assert err.max() <= TOL, err.max()
 
 
+def _random_cases(n, seed):
+    """valid points of the t41rx_params space (design.cpp: params_valid), seeded"""
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        mode = int(rng.integers(0, 4))
+        if mode == 1:
+            hi = -int(rng.integers(50, 800))
+            lo = hi - int(rng.integers(300, 5000))
+        elif mode == 2:
+            lo, hi = -int(rng.integers(1500, 6000)), int(rng.integers(1500, 6000))
+        else:
+            lo = int(rng.integers(50, 800))
+            hi = lo + int(rng.integers(300, 5000))
+        kw = dict(mode=mode, FLoCut=lo, FHiCut=hi,
+                  rfGainAllBands=int(rng.integers(-10, 11)), RFgain=int(rng.integers(1, 5)),
+                  audioVolume=int(rng.integers(5, 101)),
+                  IQAmpCorrectionFactor=float(np.float32(rng.uniform(0.9, 1.1))),
+                  IQPhaseCorrectionFactor=float(np.float32(rng.uniform(-0.05, 0.05))),
+                  xmtMode=int(rng.integers(0, 3)), CWFreqShift=int(rng.choice([562, 656, 750, 843])),
+                  AGCMode=int(rng.integers(0, 5)), AGC_thresh=int(rng.integers(10, 40)))
+        out.append(kw)
+    return out
+
+
+@pytest.mark.parametrize("kw", _random_cases(16, seed=2026), ids=lambda kw: "m%d-agc%d" % (kw["mode"], kw["AGCMode"]))
+def test_parity_random_parameter_points(T, kw):
+    """seeded random points of the parameter space, 7 channels (ragged workgroup) x 6 frames, a
+    level step in the middle so the AGC (when on) leaves its attack state"""
+    nch, nfr = 7, 6
+    nco = siggen.nco_grid(nch, seed=kw["FHiCut"] & 1023)
+    mode = kw["mode"]
+    side = 0
+    if kw["xmtMode"] == 1:
+        side = kw["CWFreqShift"] if mode == 1 else (-kw["CWFreqShift"] if mode == 0 else 0)
+    if mode == 3:
+        I, Q = siggen.make_fm(nch, nfr * L, nco + side, seed=kw["FLoCut"] & 255)
+    else:
+        lo, hi = (abs(kw["FHiCut"]), abs(kw["FLoCut"])) if mode == 1 else (max(kw["FLoCut"], 100), kw["FHiCut"])
+        band = (lo + 0.15 * (hi - lo), lo + 0.85 * (hi - lo))
+        I, Q = siggen.make_iq(nch, nfr * L, nco + side, mode=mode, seed=kw["audioVolume"], audio_hz=band)
+    I, Q = siggen.fade(I, Q, [(0.5, 1.0), (0.5, 0.2)])
+    got, _ = gpu_run(T, kw, nco, I, Q)
+    ref = oracle_run(kw, nco, I, Q)
+    err = siggen.block_rel_err(got, ref, L)
+    assert np.isfinite(got).all()
+    assert err.max() <= (AM_TOL if mode == 2 else TOL), (kw, err.max(), np.unravel_index(err.argmax(), err.shape))
+
+
 def test_parity_fft4096(T):
     """BASELINE config 4 (synthetic generalisation): FFT_LENGTH 4096, 16384-sample
     frames, 2049-tap narrow USB filter (400..600 Hz), three-kernel pipeline"""

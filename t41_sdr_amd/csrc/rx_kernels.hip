@@ -825,10 +825,15 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
   auto stage_tables = [&]() {
     const float4 *src = reinterpret_cast<const float4 *>(a.tab);
     float4 *dst = reinterpret_cast<float4 *>(smem);
-#pragma unroll
-    for (int i = threadIdx.x; i < (512 + 448) / 2; i += 256) dst[i] = src[i];  // mask, tw1
-    if (threadIdx.x < 56)  // tw2[q][l1] = table entry [q][lane = l1]
-      reinterpret_cast<float2 *>(smem)[kLdsTabTw2 + threadIdx.x] = a.tab[kTabTw2 + 64 * (threadIdx.x >> 3) + (threadIdx.x & 7)];
+    if (PART == 1) {
+      // the 4096 front end has no FFT: the mask's place holds the oscillator's (cos, sin) table,
+      // whose per-sub-block lookup is otherwise a global load nothing hides at 4 waves per CU
+      if (threadIdx.x < 128) dst[threadIdx.x] = reinterpret_cast<const float4 *>(a.tab + kTabSinCos)[threadIdx.x];
+    } else {
+      for (int i = threadIdx.x; i < (512 + 448) / 2; i += 256) dst[i] = src[i];  // mask, tw1
+      if (threadIdx.x < 56)  // tw2[q][l1] = table entry [q][lane = l1]
+        reinterpret_cast<float2 *>(smem)[kLdsTabTw2 + threadIdx.x] = a.tab[kTabTw2 + 64 * (threadIdx.x >> 3) + (threadIdx.x & 7)];
+    }
     __syncthreads();
   };
   // per-lane constants of the DC high-pass scan
@@ -864,6 +869,10 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
   bool transient = false;
 
   f2 dc2 = splat(0.0f);  // DC high-pass carries, see below
+  // input registers, two sub-blocks in flight (even / odd).  They live across iterations because
+  // the 4096 front end (PART 1: 8 segments per frame, only 4 waves per CU to hide anything)
+  // requests the NEXT segment's first two sub-blocks while it finishes the current one.
+  float4 pI0[2], pI1[2], pQ0[2], pQ1[2];
 #ifdef T41RX_STAMP
   unsigned long long stamp_acc = 0, stamp_last;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
@@ -904,13 +913,17 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
       // ---- first loads of the frame, issued in the order they are needed (vmcnt retires in
       // order): sub-block 0, the I tail for Q's DC-block start state, the delay lines, then
       // sub-block 1.  Input prefetch runs TWO sub-blocks ahead (two register sets, even / odd).
-      float4 pI0[2], pI1[2], pQ0[2], pQ1[2];
+      // PART 1, second and later segments of a call: the inputs are already on their way and the
+      // delay lines are still in LDS where the history rolls left them
+      const bool carried = (PART == 1) && f > 0;
       float4 tailI;
       if (!WQ15) {
-        pI0[0] = ldg_stream(gI + 8 * lane);
-        pI1[0] = ldg_stream(gI + 8 * lane + 4);
-        pQ0[0] = ldg_stream(gQ + 8 * lane);
-        pQ1[0] = ldg_stream(gQ + 8 * lane + 4);
+        if (!carried) {
+          pI0[0] = ldg_stream(gI + 8 * lane);
+          pI1[0] = ldg_stream(gI + 8 * lane + 4);
+          pQ0[0] = ldg_stream(gQ + 8 * lane);
+          pQ1[0] = ldg_stream(gQ + 8 * lane + 4);
+        }
         tailI = *reinterpret_cast<const float4 *>(gI + (L - 256) + 4 * lane);
       } else {  // 8 samples = 16 bytes per lane and array
         pI0[0] = ldg_stream(gI + 4 * lane);
@@ -919,14 +932,17 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
         tailI = make_float4(q15_lo(t.x), q15_hi(t.x), q15_lo(t.y), q15_hi(t.y));
       }
       float4 h1 = make_float4(0, 0, 0, 0), h2 = make_float4(0, 0, 0, 0);
-      if (lane < 14) h1 = *reinterpret_cast<const float4 *>(st + kStDec1 + 4 * lane);
-      if (lane < 24) h2 = *reinterpret_cast<const float4 *>(st + kStDec2 + 4 * lane);
+      if (!carried) {
+        if (lane < 14) h1 = *reinterpret_cast<const float4 *>(st + kStDec1 + 4 * lane);
+        if (lane < 24) h2 = *reinterpret_cast<const float4 *>(st + kStDec2 + 4 * lane);
+      }
       // gains (Process.cpp:117-134, 165-166).  g_band and -IQAmp are folded into one factor on I
       // (exact whenever either is +-1, which is the firmware default; one rounding otherwise)
       float g_rf, g_rf_i, iq_phase_neg = 0.0f, iq_phase_pos = 0.0f;
       f2 g_iq = splat(1.0f);
       {
-        const CoefPtr c = fresh_coef(cf0);
+        // (PART 1: plain pointer -- the loads are loop invariant and leave the segment loop)
+        const CoefPtr c = (PART == 1) ? cf0 : fresh_coef(cf0);
         g_rf = c->sc[kScRfGain];
         if (WQ15) g_rf *= 1.0f / 32768.0f;  // arm_q15_to_float
         // PLAIN: sign of the I path (-1 when the IQ amplitude correction applies, Process.cpp:165-173)
@@ -944,10 +960,12 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
       if (f == 0) stage_tables();
       STAMP(17);  // prologue b: table staging + workgroup barrier (first vmcnt wait)
       if (!WQ15) {
-        pI0[1] = ldg_stream(gI + 512 + 8 * lane);
-        pI1[1] = ldg_stream(gI + 512 + 8 * lane + 4);
-        pQ0[1] = ldg_stream(gQ + 512 + 8 * lane);
-        pQ1[1] = ldg_stream(gQ + 512 + 8 * lane + 4);
+        if (!carried) {
+          pI0[1] = ldg_stream(gI + 512 + 8 * lane);
+          pI1[1] = ldg_stream(gI + 512 + 8 * lane + 4);
+          pQ0[1] = ldg_stream(gQ + 512 + 8 * lane);
+          pQ1[1] = ldg_stream(gQ + 512 + 8 * lane + 4);
+        }
       } else {
         pI0[1] = ldg_stream(gI + 256 + 4 * lane);
         pQ0[1] = ldg_stream(gQ + 256 + 4 * lane);
@@ -955,8 +973,10 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
 
       // ---- delay lines -> LDS (every frame is self-contained: load state, run, store state)
       wave_sync();
-      if (lane < 14) *reinterpret_cast<float4 *>(lds + kX + 2 * xpad(2 * lane)) = h1;
-      if (lane < 24) *reinterpret_cast<float4 *>(lds + kY1 + 4 * lane) = h2;
+      if (!carried) {
+        if (lane < 14) *reinterpret_cast<float4 *>(lds + kX + 2 * xpad(2 * lane)) = h1;
+        if (lane < 24) *reinterpret_cast<float4 *>(lds + kY1 + 4 * lane) = h2;
+      }
       STAMP(18);  // prologue c: delay lines -> LDS
       if (f == 0) {
         dphi = uniform_u64(raw_dphi);
@@ -1019,6 +1039,14 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
               pI0[h] = ldg_stream(gI + o);
               pQ0[h] = ldg_stream(gQ + o);
             }
+          } else if (PART == 1) {  // the next segment's sub-blocks 0 and 1 (same channel: contiguous)
+            if (f + 1 < a.nframes) {
+              const int o = L + 512 * (s - 2) + 8 * lane;
+              pI0[h] = ldg_stream(gI + o);
+              pI1[h] = ldg_stream(gI + o + 4);
+              pQ0[h] = ldg_stream(gQ + o);
+              pQ1[h] = ldg_stream(gQ + o + 4);
+            }
           } else if (s == 3) {  // last sub-block: prefetch the overlap-save "previous" block instead
             const cf *ov = reinterpret_cast<const cf *>(st + kStOverlap);
   #pragma unroll
@@ -1069,7 +1097,7 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
           cf base;
           {
             const uint64_t P = phase0 + (uint64_t)(n0 + 1) * dphi;
-            const float2 t = tab[kTabSinCos + (int)(P >> 56)];
+            const float2 t = (PART == 1) ? reinterpret_cast<const float2 *>(smem)[(int)(P >> 56)] : tab[kTabSinCos + (int)(P >> 56)];
             const uint32_t u = (uint32_t)(P >> 24);
             const float ang = (float)u * (float)(6.283185307179586476925 / 256.0 / 4294967296.0);
             const float a2 = ang * ang;
@@ -1080,7 +1108,8 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
           // -- Fs/4 shift (x j^n, Freq_Shift.cpp:42-65) and NCO mix (Freq_Shift.cpp:138-139):
           //    (I' + jQ') = (I + jQ) j^k conj(Osc_k) = (I + jQ) conj(base wk''),  wk'' = wk (-j)^k
           //    (the host pre-rotates the per-channel constants, so the Fs/4 shift costs nothing)
-          const NcoPtr ncw = fresh_nco(nco);
+          // (PART 1: plain pointer, so the 16 scalar loads are hoisted out of the sub-block loop)
+          const NcoPtr ncw = (PART == 1) ? nco : fresh_nco(nco);
   #pragma unroll
           for (int k = 0; k < 8; ++k) {
             const cf w = cf{ncw->wk[k][0], ncw->wk[k][1]};
@@ -1158,8 +1187,10 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
       wave_sync();
       if (lane < 14) *reinterpret_cast<float4 *>(st + kStDec1 + 4 * lane) = lds4(lds + kX + 2 * xpad(2 * lane));
       if (lane < 24) *reinterpret_cast<float4 *>(st + kStDec2 + 4 * lane) = lds4(lds + kY1 + 4 * lane);
-      if (lane < 6) hist1 = *reinterpret_cast<const float4 *>(st + kStInt1 + 4 * lane);
-      if (lane < 8) hist2 = st[kStInt2 + lane];
+      if (PART != 1) {
+        if (lane < 6) hist1 = *reinterpret_cast<const float4 *>(st + kStInt1 + 4 * lane);
+        if (lane < 8) hist2 = st[kStInt2 + lane];
+      }
       if (AGC && lane < 52) agst = *reinterpret_cast<const float4 *>(st + st_agc(kStateN) + 4 * lane);
       wave_sync();
 
@@ -1537,7 +1568,7 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt)::"memory");
     if (lane == 29) stamp_acc = rt;
   }
-  if (a.dbg_demod)
+  if (a.dbg_demod && PART != 2)  // (4096 pipeline: the front kernel's stamps)
     reinterpret_cast<unsigned long long *>(a.dbg_demod + (size_t)a.nchan * a.nframes * D)[(size_t)ch * 64 + lane] = stamp_acc;
 #endif
 
@@ -1550,24 +1581,29 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
 
 // ------------------------------------------------------------------------------------------
 // FFT_LENGTH 4096 (BASELINE config 4, a synthetic generalisation: the firmware is compiled for
-// 512): overlap-save fast convolution of one channel per wave.  4096 = 8 x 512:
+// 512): overlap-save fast convolution, one channel per 4-wave workgroup.  4096 = 8 x 512:
 //   pass 1 (DIF radix-8 over p, x[k' + 512 p]): DFT8, twiddle W4096^(k' q)  -> Z[q][k'] in place
 //   pass 2 per q: fft512 over k' -> X[q + 8 m]; x mask; inverse fft512 over m -> W[q][k'] in place
 //   pass 3 (inverse of pass 1): conj twiddle, inverse DFT8 over q -> y[k' + 512 p], natural order
 // The 4096-point working array lives in LDS (32 KiB, every access is lane-contiguous), the
-// 512-point sub-FFTs are the same register/LDS-exchange code as the 512 path.
+// 512-point sub-FFTs are the same register/LDS-exchange code as the 512 path.  Each pass is 8
+// independent pieces (column blocks / rows): wave w takes pieces w and w + 4, workgroup barriers
+// separate the passes.  (One wave per channel left a CU with 4 latency-bound waves: 28.5 us for
+// 1024 channels; four per channel: 3 workgroups = 12 waves per CU.)
 // ------------------------------------------------------------------------------------------
 constexpr int kFcArrayFloats = 2 * 4096;
-constexpr int kFcLdsFloats = kFcArrayFloats + 8 * kFftRow * 2;  // + fft512 exchange scratch
+constexpr int kFcXbufFloats = 8 * kFftRow * 2;                   // fft512 exchange scratch, one per wave
+constexpr int kFcLdsFloats = kFcArrayFloats + 4 * kFcXbufFloats;
 
-__global__ __launch_bounds__(64) void fastconv4096_kernel(const RxArgs a) {
+__global__ __launch_bounds__(256) void fastconv4096_kernel(const RxArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int N = 4096, D = 2048;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ch = blockIdx.x;
   if (ch >= a.nchan) return;
   cf *A = reinterpret_cast<cf *>(smem);
-  float *xbuf = smem + kFcArrayFloats;
+  float *xbuf = smem + kFcArrayFloats + wv * kFcXbufFloats;
   float *st = a.state + (size_t)ch * state_floats(N);
   const cf *tw4k = reinterpret_cast<const cf *>(a.tab4k) + kTab4kTw;
   const cf *mask4k = reinterpret_cast<const cf *>(a.tab4k) + kTab4kMask;
@@ -1586,19 +1622,19 @@ __global__ __launch_bounds__(64) void fastconv4096_kernel(const RxArgs a) {
     const float4 *prev = reinterpret_cast<const float4 *>(st + kStOverlap);
     const float4 *mid = reinterpret_cast<const float4 *>(a.mid + ((size_t)ch * a.nframes4k + f) * (2 * D));
     float4 *A4 = reinterpret_cast<float4 *>(smem);
-    wave_sync();
-#pragma unroll 4
-    for (int i = 0; i < 16; ++i) {
+    __syncthreads();  // the previous frame's pass 3 is done with the array
+#pragma unroll
+    for (int i = wv; i < 16; i += 4) {
       const float4 p = prev[64 * i + lane];
       const float4 n = mid[64 * i + lane];
       A4[64 * i + lane] = p;
       A4[1024 + 64 * i + lane] = n;
       reinterpret_cast<float4 *>(st + kStOverlap)[64 * i + lane] = n;  // next frame's "previous"
     }
-    wave_sync();
+    __syncthreads();
     // ---- pass 1
 #pragma unroll 1
-    for (int r = 0; r < 8; ++r) {
+    for (int r = wv; r < 8; r += 4) {
       const int k = lane + 64 * r;
       cf v[8];
 #pragma unroll
@@ -1609,10 +1645,10 @@ __global__ __launch_bounds__(64) void fastconv4096_kernel(const RxArgs a) {
 #pragma unroll
       for (int q = 0; q < 8; ++q) A[k + 512 * q] = v[q];
     }
-    wave_sync();
+    __syncthreads();
     // ---- pass 2: 512-point FFT, mask (pre-scaled by 1/4096), inverse 512-point FFT, per q
 #pragma unroll 1
-    for (int q = 0; q < 8; ++q) {
+    for (int q = wv; q < 8; q += 4) {
       cf v[8];
 #pragma unroll
       for (int r = 0; r < 8; ++r) v[r] = A[512 * q + lane + 64 * r];
@@ -1623,11 +1659,11 @@ __global__ __launch_bounds__(64) void fastconv4096_kernel(const RxArgs a) {
 #pragma unroll
       for (int r = 0; r < 8; ++r) A[512 * q + lane + 64 * r] = v[r];
     }
-    wave_sync();
+    __syncthreads();
     // ---- pass 3; AGC off: fixed gain (DSP_Fn.cpp:494-502); SSB: audio = Re of the valid half
     float *au = a.aud24 + ((size_t)ch * a.nframes4k + f) * D;
 #pragma unroll 1
-    for (int r = 0; r < 8; ++r) {
+    for (int r = wv; r < 8; r += 4) {
       const int k = lane + 64 * r;
       cf v[8];
 #pragma unroll
@@ -1683,7 +1719,7 @@ static hipError_t launch4096(const RxArgs &a, hipStream_t s) {
   hipLaunchKernelGGL((rx512_kernel<kModeSsb, false, 1, false>), dim3(grid), dim3(256), 40960, s, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(fastconv4096_kernel, dim3(a.nchan), dim3(64), kFcLdsFloats * sizeof(float), s, a);
+  hipLaunchKernelGGL(fastconv4096_kernel, dim3(a.nchan), dim3(256), kFcLdsFloats * sizeof(float), s, a);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL((rx512_kernel<kModeSsb, false, 2, false>), dim3(grid), dim3(256), 40960, s, a);

@@ -23,9 +23,11 @@ NAMES = ["wait loads + gain", "DC high-pass", "NCO + mix", "LDS stage + /4 FIR",
 
 def main():
     nch = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-    L, D = 2048, 256
     agc = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    rx = T.RxChain(nch, T.default_params(AGCMode=agc), NCOFreq=np.full(nch, 5000, np.int32))
+    fft = int(sys.argv[3]) if len(sys.argv) > 3 else 512  # 4096: stamps of the front kernel (8 segments)
+    L, D = 4 * fft, (256 if fft == 512 else 8 * 256)
+    kw = dict(AGCMode=agc) if fft == 512 else dict(fft_length=4096, FLoCut=400, FHiCut=600)
+    rx = T.RxChain(nch, T.default_params(**kw), NCOFreq=np.full(nch, 5000, np.int32))
     g = torch.Generator(device="cuda").manual_seed(0)
     I = 0.2 * torch.randn(nch, L, generator=g, device="cuda")
     Q = 0.2 * torch.randn(nch, L, generator=g, device="cuda")

@@ -840,7 +840,7 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
   const float2 hp8 = a.tab[kTabHp8 + lane];
   const float2 hp4 = a.tab[kTabHp4 + lane];
   if (ch >= a.nchan) {  // ragged last workgroup: help with the staging, meet the barrier, leave
-    stage_tables();
+    if (PART != 2) stage_tables();
     return;
   }
 
@@ -873,6 +873,9 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
   // the 4096 front end (PART 1: 8 segments per frame, only 4 waves per CU to hide anything)
   // requests the NEXT segment's first two sub-blocks while it finishes the current one.
   float4 pI0[2], pI1[2], pQ0[2], pQ1[2];
+  // PART 2 (4096 back end, same situation): interpolator histories and the next segment's audio
+  float4 hist1c = make_float4(0, 0, 0, 0);
+  float hist2c = 0.0f, audn[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #ifdef T41RX_STAMP
   unsigned long long stamp_acc = 0, stamp_last;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
@@ -904,11 +907,21 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
       // back half of the 4096 pipeline: this segment's 256 audio samples come from the
       // fast-convolution kernel
       const float *au = a.aud24 + ((size_t)ch * a.nframes + f) * D;
+      if (f == 0) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) aud[j] = au[lane + 64 * j];
-      if (lane < 6) hist1 = *reinterpret_cast<const float4 *>(st + kStInt1 + 4 * lane);
-      if (lane < 8) hist2 = st[kStInt2 + lane];
-      if (f == 0) stage_tables();
+        for (int j = 0; j < 4; ++j) aud[j] = au[lane + 64 * j];
+        if (lane < 6) hist1 = *reinterpret_cast<const float4 *>(st + kStInt1 + 4 * lane);
+        if (lane < 8) hist2 = st[kStInt2 + lane];
+      } else {  // requested / kept during the previous segment
+#pragma unroll
+        for (int j = 0; j < 4; ++j) aud[j] = audn[j];
+        hist1 = hist1c;
+        hist2 = hist2c;
+      }
+      if (f + 1 < a.nframes) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) audn[j] = au[D + lane + 64 * j];
+      }
     } else {
       // ---- first loads of the frame, issued in the order they are needed (vmcnt retires in
       // order): sub-block 0, the I tail for Q's DC-block start state, the delay lines, then
@@ -1470,7 +1483,10 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
         w[4 * i + 2] = t.z;
         w[4 * i + 3] = t.w;
       }
-      if (lane < 6) *reinterpret_cast<float4 *>(st + kStInt1 + 4 * lane) = lds4(lds + 256 + 4 * lane);
+      if (lane < 6) {
+        hist1c = lds4(lds + 256 + 4 * lane);
+        *reinterpret_cast<float4 *>(st + kStInt1 + 4 * lane) = hist1c;
+      }
       // arm_fir_interpolate_f32: out[2n + j - 1] = sum_t state[n + t] * c[(2 - j) + 2 t]:
       // (out[2n], out[2n+1]) += state[n+t] * (c[2t+1], c[2t])  -- one packed FMA per tap
 #pragma unroll
@@ -1506,6 +1522,13 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
       if (lane == 63) {
         *reinterpret_cast<float4 *>(st + kStInt2) = make_float4(0.0f, x1[1], x1[2], x1[3]);
         *reinterpret_cast<float4 *>(st + kStInt2 + 4) = make_float4(x1[4], x1[5], x1[6], x1[7]);
+      }
+      if (PART == 2) {  // the same seven values, kept for the next segment: lane i = entry i
+#pragma unroll
+        for (int i = 1; i < 8; ++i) {
+          const float t = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x1[i]), 63));
+          hist2c = (lane == i) ? t : hist2c;
+        }
       }
       // out[4n + j - 1] = sum_t state[n + t] * c[(4 - j) + 4 t],  state[n + t] = w[u + t]:
       // (out[4n], out[4n+1]) += w * (c[4t+3], c[4t+2]);  (out[4n+2], out[4n+3]) += w * (c[4t+1], c[4t])

@@ -360,6 +360,31 @@ def test_silence_and_full_scale_inputs(T):
     assert siggen.block_rel_err(got, oracle_run(dict(), nco, I, Q), L).max() <= TOL
 
 
+@pytest.mark.parametrize("agcmode", [1, 4])
+def test_agc_edge_inputs(T, agcmode):
+    """AGC on with silence (volts rests on min_volts, the gain stays finite, audio exactly 0), silence
+    followed by a full-scale burst (the 97-sample look-ahead meets it) and back to silence"""
+    nch = 5
+    nco = np.array([0, 1000, -30000, 40000, 5000], np.int32)
+    kw = dict(AGCMode=agcmode)
+    Z = np.zeros((nch, 2 * L), np.float32)
+    got, rx = gpu_run(T, kw, nco, Z, Z)
+    assert np.array_equal(got, np.zeros_like(got))
+    st = rx.get_state().view(np.float32).reshape(nch, -1)
+    assert np.all(st[:, 768 + 200 + 2] == np.float32(O.coeff_arrays(O.design(O.default_params(**kw)), 512)["agc"][9]))  # min_volts
+    rng = np.random.default_rng(1)
+    I = np.sign(rng.standard_normal((nch, 6 * L))).astype(np.float32) * 0.999
+    Q = np.sign(rng.standard_normal((nch, 6 * L))).astype(np.float32) * 0.999
+    I[:, :2 * L] = 0
+    Q[:, :2 * L] = 0
+    I[:, 4 * L + 300:] = 0
+    Q[:, 4 * L + 300:] = 0
+    got, _ = gpu_run(T, kw, nco, I, Q)
+    ref = oracle_run(kw, nco, I, Q)
+    assert np.isfinite(got).all()
+    assert siggen.block_rel_err(got, ref, L).max() <= TOL
+
+
 def test_argument_errors(T):
     import torch
     from t41_sdr_amd import _lib

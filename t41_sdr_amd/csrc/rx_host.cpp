@@ -445,6 +445,11 @@ int process_device_impl(t41rx_ctx *ctx, const float *dI, const float *dQ, float 
     const float *sc = blob_view(ctx->blob.data()).scalars;
     const bool iq_on = sc[kScIqCorrOn] != 0.0f;
     const float gi = iq_on ? sc[kScBandGain] * sc[kScNegIqAmp] : sc[kScBandGain];
+    a.g_rf = sc[kScRfGain];
+    a.g_band = sc[kScBandGain];
+    a.neg_iq_amp = sc[kScNegIqAmp];
+    a.iq_phase = sc[kScIqPhase];
+    a.iq_corr_on = iq_on ? 1 : 0;
     a.plain = ((gi == 1.0f || (iq_on && gi == -1.0f)) && sc[kScBandGain] == 1.0f && (!iq_on || sc[kScIqPhase] == 0.0f)) ? 1 : 0;
   }
   a.q15 = q15 ? 1 : 0;

@@ -954,17 +954,15 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
       float g_rf, g_rf_i, iq_phase_neg = 0.0f, iq_phase_pos = 0.0f;
       f2 g_iq = splat(1.0f);
       {
-        // (PART 1: plain pointer -- the loads are loop invariant and leave the segment loop)
-        const CoefPtr c = (PART == 1) ? cf0 : fresh_coef(cf0);
-        g_rf = c->sc[kScRfGain];
+        g_rf = a.g_rf;
         if (WQ15) g_rf *= 1.0f / 32768.0f;  // arm_q15_to_float
         // PLAIN: sign of the I path (-1 when the IQ amplitude correction applies, Process.cpp:165-173)
-        g_rf_i = (PLAIN && c->sc[kScIqCorrOn] != 0.0f) ? -g_rf : g_rf;
+        g_rf_i = (PLAIN && a.iq_corr_on) ? -g_rf : g_rf;
         if (!PLAIN) {
-          const float gb = c->sc[kScBandGain];
-          const bool iq_on = c->sc[kScIqCorrOn] != 0.0f;
-          g_iq = f2{iq_on ? gb * c->sc[kScNegIqAmp] : gb, gb};
-          const float ph = iq_on ? c->sc[kScIqPhase] : 0.0f;
+          const float gb = a.g_band;
+          const bool iq_on = a.iq_corr_on != 0;
+          g_iq = f2{iq_on ? gb * a.neg_iq_amp : gb, gb};
+          const float ph = iq_on ? a.iq_phase : 0.0f;
           iq_phase_neg = ph < 0.0f ? ph : 0.0f;
           iq_phase_pos = ph > 0.0f ? ph : 0.0f;
         }

@@ -40,6 +40,13 @@ struct RxArgs {
   int nframes4k;           // number of 4096-frames (= nframes / 8 for the part kernels)
   int plain;               // 1: unit band/IQ gains and zero IQ phase correction -> specialised kernel
   int agc;                 // 1: AGCMode != 0 (look-ahead AGC, DSP_Fn.cpp:504-631)
+  // the gains of the first stage, by value: a kernel argument is one scalar-load round trip away
+  // at kernel start, a field behind `coef` is two
+  float g_rf;              // sc[kScRfGain]
+  float g_band;            // sc[kScBandGain]
+  float neg_iq_amp;        // sc[kScNegIqAmp]
+  float iq_phase;          // sc[kScIqPhase]
+  int iq_corr_on;          // sc[kScIqCorrOn] != 0
   int q15;                 // 1: I, Q, out point at int16 (q15) samples instead of f32 (Process.cpp:102-111, 936)
 };
 

@@ -128,7 +128,7 @@ int upload_coeffs(t41rx_ctx *ctx) {
   std::memcpy(dc.agc, v.agc, sizeof(float) * kNumAgc);
   HIP_TRY(hipMemcpy(ctx->d_coef, &dc, sizeof(dc), hipMemcpyHostToDevice));
 
-  if (N != 512 && N != 4096) return fail(T41RX_ERR_UNSUPPORTED, "only fft_length 512 and 4096 have kernels");
+  const int R = N / 512;  // 2048-sample segments per frame
   std::vector<float2> tab((size_t)kTabEntries512, make_float2(0.0f, 0.0f));
   const float invN = 1.0f / (float)N;  // exact power of two: folding it into the mask is lossless
   if (N == 512) {
@@ -138,18 +138,18 @@ int upload_coeffs(t41rx_ctx *ctx) {
         tab[(size_t)(kTabMask + 64 * r + l)] = make_float2(v.mask[2 * k] * invN, v.mask[2 * k + 1] * invN);
       }
   } else {
-    // 4096 = 8 x 512 decomposition: radix-8 twiddles W4096^(k' q) and the mask in [q][m] order
-    std::vector<float2> t4((size_t)kTab4kEntries);
+    // N = R x 512 decomposition: radix-R twiddles W_N^(k' q) and the mask in [q][m] order
+    std::vector<float2> t4((size_t)tab_long_entries(R));
     const double tp = 6.283185307179586476925286766559;
-    for (int q = 1; q < 8; ++q)
+    for (int q = 1; q < R; ++q)
       for (int k = 0; k < 512; ++k) {
-        const double a = -tp * (double)(k * q) / 4096.0;
-        t4[(size_t)(kTab4kTw + 512 * (q - 1) + k)] = make_float2((float)std::cos(a), (float)std::sin(a));
+        const double a = -tp * (double)(k * q) / (double)N;
+        t4[(size_t)(512 * (q - 1) + k)] = make_float2((float)std::cos(a), (float)std::sin(a));
       }
-    for (int q = 0; q < 8; ++q)
+    for (int q = 0; q < R; ++q)
       for (int m = 0; m < 512; ++m) {
-        const int k = q + 8 * m;
-        t4[(size_t)(kTab4kMask + 512 * q + m)] = make_float2(v.mask[2 * k] * invN, v.mask[2 * k + 1] * invN);
+        const int k = q + R * m;
+        t4[(size_t)((R - 1) * 512 + 512 * q + m)] = make_float2(v.mask[2 * k] * invN, v.mask[2 * k + 1] * invN);
       }
     HIP_TRY(hipMemcpy(ctx->d_tab4k, t4.data(), sizeof(float2) * t4.size(), hipMemcpyHostToDevice));
   }
@@ -223,7 +223,9 @@ const char *t41rx_strerror(int status) {
 
 const char *t41rx_last_error(void) { return g_last_error.c_str(); }
 
-int t41rx_supported_fft_length(int fft_length) { return (fft_length == 512 || fft_length == 4096) ? 1 : 0; }
+int t41rx_supported_fft_length(int fft_length) {
+  return (fft_length == 512 || fft_length == 1024 || fft_length == 2048 || fft_length == 4096) ? 1 : 0;
+}
 
 void t41rx_default_params(t41rx_params *p) {
   if (!p) return;
@@ -266,8 +268,8 @@ int t41rx_create(t41rx_ctx **out, int device_id, int n_channels, const t41rx_par
   if (!params_valid(*p, &why)) return fail(T41RX_ERR_ARG, why ? why : "bad params");
   if (p->AGCMode != 0 && p->fft_length != 512) return fail(T41RX_ERR_UNSUPPORTED, "AGC on is built for fft_length 512 only");
   if (!t41rx_supported_fft_length(p->fft_length)) return fail(T41RX_ERR_UNSUPPORTED, "no kernel for this fft_length");
-  if (p->fft_length == 4096 && !(p->mode == T41RX_DEMOD_USB || p->mode == T41RX_DEMOD_LSB))
-    return fail(T41RX_ERR_UNSUPPORTED, "fft_length 4096 is built for USB/LSB only");
+  if (p->fft_length != 512 && !(p->mode == T41RX_DEMOD_USB || p->mode == T41RX_DEMOD_LSB))
+    return fail(T41RX_ERR_UNSUPPORTED, "fft_length 1024/2048/4096 are built for USB/LSB only");
   int ndev = 0;
   HIP_TRY(hipGetDeviceCount(&ndev));
   if (device_id < 0 || device_id >= ndev) return fail(T41RX_ERR_HIP, "no such HIP device");
@@ -292,7 +294,7 @@ int t41rx_create(t41rx_ctx **out, int device_id, int n_channels, const t41rx_par
       (e = hipMalloc((void **)&ctx->d_coef, sizeof(DevCoef))) != hipSuccess ||
       (e = hipMalloc((void **)&ctx->d_tab, sizeof(float2) * kTabEntries512)) != hipSuccess ||
       (e = hipMalloc((void **)&ctx->d_nco, sizeof(ChanNco) * (size_t)n_channels)) != hipSuccess ||
-      (p->fft_length == 4096 && (e = hipMalloc((void **)&ctx->d_tab4k, sizeof(float2) * kTab4kEntries)) != hipSuccess)) {
+      (p->fft_length != 512 && (e = hipMalloc((void **)&ctx->d_tab4k, sizeof(float2) * tab_long_entries(p->fft_length / 512))) != hipSuccess)) {
     free_ctx(ctx);
     return hip_fail(e, "hipMalloc");
   }
@@ -319,8 +321,8 @@ int t41rx_set_params(t41rx_ctx *ctx, const t41rx_params *p) {
   if (!params_valid(*p, &why)) return fail(T41RX_ERR_ARG, why ? why : "bad params");
   if (p->fft_length != ctx->params.fft_length) return fail(T41RX_ERR_ARG, "fft_length cannot change on a live context");
   if (p->AGCMode != 0 && p->fft_length != 512) return fail(T41RX_ERR_UNSUPPORTED, "AGC on is built for fft_length 512 only");
-  if (p->fft_length == 4096 && !(p->mode == T41RX_DEMOD_USB || p->mode == T41RX_DEMOD_LSB))
-    return fail(T41RX_ERR_UNSUPPORTED, "fft_length 4096 is built for USB/LSB only");
+  if (p->fft_length != 512 && !(p->mode == T41RX_DEMOD_USB || p->mode == T41RX_DEMOD_LSB))
+    return fail(T41RX_ERR_UNSUPPORTED, "fft_length 1024/2048/4096 are built for USB/LSB only");
   std::vector<float> nb(ctx->blob.size());
   int rc = design_blob(*p, nb.data(), nb.size() * sizeof(float));
   if (rc != T41RX_OK) return fail(rc, "coefficient design failed");
@@ -354,7 +356,7 @@ int t41rx_set_coeffs(t41rx_ctx *ctx, const void *blob, size_t blob_bytes) {
   if ((uint32_t)h[0] != kBlobMagic || h[1] != T41RX_ABI_VERSION) return fail(T41RX_ERR_STATE, "bad blob header");
   if (h[2] != ctx->params.fft_length) return fail(T41RX_ERR_STATE, "blob fft_length differs from the context");
   if (h[3] < T41RX_DEMOD_USB || h[3] > T41RX_DEMOD_NFM) return fail(T41RX_ERR_STATE, "bad demodulation mode in blob");
-  if (h[2] == 4096 && h[3] > T41RX_DEMOD_LSB) return fail(T41RX_ERR_UNSUPPORTED, "fft_length 4096 is built for USB/LSB only");
+  if (h[2] != 512 && h[3] > T41RX_DEMOD_LSB) return fail(T41RX_ERR_UNSUPPORTED, "fft_length 1024/2048/4096 are built for USB/LSB only");
   DeviceGuard g(ctx->device);
   HIP_TRY(hipDeviceSynchronize());
   std::memcpy(ctx->blob.data(), blob, need);
@@ -415,14 +417,15 @@ int process_device_impl(t41rx_ctx *ctx, const float *dI, const float *dQ, float 
     return fail(T41RX_ERR_ARG, "I/Q/audio device pointers must be 16-byte aligned");
   DeviceGuard g(ctx->device);
   if (!g.ok) return fail(T41RX_ERR_HIP, "hipSetDevice failed");
-  if (ctx->params.fft_length == 4096 && n_frames > ctx->scratch_frames) {
-    // scratch between the three kernels of the 4096 pipeline (grown on demand, kept)
+  const int seg = ctx->params.fft_length / 512;
+  if (seg > 1 && n_frames > ctx->scratch_frames) {
+    // scratch between the three kernels of the long-FFT pipeline (grown on demand, kept)
     HIP_TRY(hipStreamSynchronize((hipStream_t)hip_stream));
     (void)hipFree(ctx->d_mid);
     (void)hipFree(ctx->d_aud24);
     ctx->d_mid = ctx->d_aud24 = nullptr;
     ctx->scratch_frames = 0;
-    const size_t per = (size_t)ctx->nchan * (size_t)n_frames * 2048;
+    const size_t per = (size_t)ctx->nchan * (size_t)n_frames * (size_t)(256 * seg);  // fft_length / 2 per frame
     HIP_TRY(hipMalloc((void **)&ctx->d_mid, per * 2 * sizeof(float)));
     HIP_TRY(hipMalloc((void **)&ctx->d_aud24, per * sizeof(float)));
     ctx->scratch_frames = n_frames;
@@ -436,7 +439,8 @@ int process_device_impl(t41rx_ctx *ctx, const float *dI, const float *dQ, float 
   a.tab = ctx->d_tab;
   a.nco = ctx->d_nco;
   a.nchan = ctx->nchan;
-  a.nframes = (ctx->params.fft_length == 4096) ? 8 * n_frames : n_frames;  // 2048-sample segments
+  a.nframes = seg * n_frames;  // 2048-sample segments
+  a.seg = seg;
   a.nframes4k = n_frames;
   a.mid = ctx->d_mid;
   a.aud24 = ctx->d_aud24;

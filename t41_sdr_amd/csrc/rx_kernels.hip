@@ -814,7 +814,9 @@ template <int MODE, bool DEBUG, int PART, bool PLAIN, bool AGC = false, bool WQ1
 __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int L = 2048, D = 256, N = 512;
-  constexpr int kStateN = (PART == 0) ? 512 : 4096;  // per-channel state record size follows fft_length
+  // per-channel state record size follows fft_length = 512 * (segments per frame)
+  const int seg = (PART == 0) ? 1 : a.seg;
+  const size_t state_stride = state_floats(512 * seg);
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ch = blockIdx.x * 4 + wv;
@@ -846,7 +848,7 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
 
   const cf *ltab = reinterpret_cast<const cf *>(smem);
   float *lds = smem + kLdsTabFloats + wv * kLdsFloatsPerWave;
-  float *st = a.state + (size_t)(T41RX_ABLATE == 9 ? (ch & 15) : ch) * state_floats(kStateN);
+  float *st = a.state + (size_t)(T41RX_ABLATE == 9 ? (ch & 15) : ch) * state_stride;
   // coefficients are read-only for the kernel: constant address space -> scalar (SMEM) loads,
   // re-derived through an opaque asm per phase so the compiler keeps the tap loads next to
   // their use instead of hoisting all 180 of them (and spilling SGPRs).
@@ -1004,8 +1006,8 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
       // frame's I and then its Q (Process.cpp:127-128): for the 4096 pipeline a frame is 8
       // segments, so the I chain runs on across segments and the Q chain starts from the state
       // after the frame's LAST I samples.
-      if (PART == 0 || (f & 7) == 0) {
-        const float4 tailF = (PART == 0) ? tailI : *reinterpret_cast<const float4 *>(gI + (8 * L - 256) + 4 * lane);
+      if (PART == 0 || (f & (seg - 1)) == 0) {
+        const float4 tailF = (PART == 0) ? tailI : *reinterpret_cast<const float4 *>(gI + (seg * L - 256) + 4 * lane);
         const float x[4] = {tailF.x * g_rf, tailF.y * g_rf, tailF.z * g_rf, tailF.w * g_rf};
         dc2 = f2{(g_rf_i != g_rf) ? -dc_carry : dc_carry, dc_highpass_end_state<4>(x, hp4.x, hp4.y)};
       }
@@ -1190,7 +1192,7 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
         }
       }  // rd
       phase0 += (uint64_t)L * dphi;
-      if (PART == 0 || (f & 7) == 7) dc_carry = uniform_f32(dc2.y);  // the shared biquad ends the frame on Q
+      if (PART == 0 || (f & (seg - 1)) == seg - 1) dc_carry = uniform_f32(dc2.y);  // the shared biquad ends the frame on Q
 
       STAMP(4);
       // ---- delay lines back to HBM (the LDS copies are about to be reused as scratch); issue
@@ -1202,7 +1204,7 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
         if (lane < 6) hist1 = *reinterpret_cast<const float4 *>(st + kStInt1 + 4 * lane);
         if (lane < 8) hist2 = st[kStInt2 + lane];
       }
-      if (AGC && lane < 52) agst = *reinterpret_cast<const float4 *>(st + st_agc(kStateN) + 4 * lane);
+      if (AGC && lane < 52) agst = *reinterpret_cast<const float4 *>(st + st_agc(512) + 4 * lane);
       wave_sync();
 
       // ---- level adjust (Process.cpp:481-492)
@@ -1314,7 +1316,7 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
       cf og[4];
       if (AGC) {
         const int left = a.nchan - 4 * (int)blockIdx.x;
-        agc_apply(v, agst, lds, smem, st + st_agc(kStateN), cf0, lane, wv, left < 4 ? left : 4, og STAMP_ARGS);
+        agc_apply(v, agst, lds, smem, st + st_agc(512), cf0, lane, wv, left < 4 ? left : 4, og STAMP_ARGS);
       }
       if (MODE != kModeAm) {
   #pragma unroll
@@ -1602,7 +1604,8 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
 
 // ------------------------------------------------------------------------------------------
 // FFT_LENGTH 4096 (BASELINE config 4, a synthetic generalisation: the firmware is compiled for
-// 512): overlap-save fast convolution, one channel per 4-wave workgroup.  4096 = 8 x 512:
+// 512; 1024 and 2048 likewise with R = 2, 4 in place of 8): overlap-save fast convolution, one
+// channel per 4-wave workgroup.  4096 = 8 x 512:
 //   pass 1 (DIF radix-8 over p, x[k' + 512 p]): DFT8, twiddle W4096^(k' q)  -> Z[q][k'] in place
 //   pass 2 per q: fft512 over k' -> X[q + 8 m]; x mask; inverse fft512 over m -> W[q][k'] in place
 //   pass 3 (inverse of pass 1): conj twiddle, inverse DFT8 over q -> y[k' + 512 p], natural order
@@ -1612,22 +1615,42 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
 // separate the passes.  (One wave per channel left a CU with 4 latency-bound waves: 28.5 us for
 // 1024 channels; four per channel: 3 workgroups = 12 waves per CU.)
 // ------------------------------------------------------------------------------------------
-constexpr int kFcArrayFloats = 2 * 4096;
-constexpr int kFcXbufFloats = 8 * kFftRow * 2;                   // fft512 exchange scratch, one per wave
-constexpr int kFcLdsFloats = kFcArrayFloats + 4 * kFcXbufFloats;
+constexpr int kFcXbufFloats = 8 * kFftRow * 2;  // fft512 exchange scratch, one per wave
+constexpr int fc_lds_floats(int R) { return 2 * 512 * R + 4 * kFcXbufFloats; }
 
-__global__ __launch_bounds__(256) void fastconv4096_kernel(const RxArgs a) {
+template <int R, bool INV>
+__device__ __forceinline__ void dft_r(cf (&v)[R]) {
+  if constexpr (R == 8) {
+    dft8<INV>(v);
+  } else if constexpr (R == 4) {
+    const cf a0 = v[0] + v[2], a1 = v[0] - v[2], a2 = v[1] + v[3];
+    // -j (v1 - v3) forward, +j (v1 - v3) inverse
+    const cf d = v[1] - v[3];
+    v[0] = a0 + a2;
+    v[2] = a0 - a2;
+    v[1] = INV ? add_pj(a1, d) : add_mj(a1, d);
+    v[3] = INV ? add_mj(a1, d) : add_pj(a1, d);
+  } else {
+    const cf a0 = v[0] + v[1], a1 = v[0] - v[1];
+    v[0] = a0;
+    v[1] = a1;
+  }
+}
+
+// N = 512 R, R = 2, 4, 8 (FFT_LENGTH 1024, 2048, 4096)
+template <int R>
+__global__ __launch_bounds__(256) void fastconv_kernel(const RxArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int N = 4096, D = 2048;
+  constexpr int N = 512 * R, D = N / 2;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ch = blockIdx.x;
   if (ch >= a.nchan) return;
   cf *A = reinterpret_cast<cf *>(smem);
-  float *xbuf = smem + kFcArrayFloats + wv * kFcXbufFloats;
+  float *xbuf = smem + 2 * N + wv * kFcXbufFloats;
   float *st = a.state + (size_t)ch * state_floats(N);
-  const cf *tw4k = reinterpret_cast<const cf *>(a.tab4k) + kTab4kTw;
-  const cf *mask4k = reinterpret_cast<const cf *>(a.tab4k) + kTab4kMask;
+  const cf *twN = reinterpret_cast<const cf *>(a.tab4k);                    // [R-1][512]
+  const cf *maskN = reinterpret_cast<const cf *>(a.tab4k) + (R - 1) * 512;  // [R][512]
   const cf *tab = reinterpret_cast<const cf *>(a.tab);
   const float fixed_gain = ((CoefPtr)a.coef)->sc[kScFixedGain];
 
@@ -1639,17 +1662,17 @@ __global__ __launch_bounds__(256) void fastconv4096_kernel(const RxArgs a) {
   }
 
   for (int f = 0; f < a.nframes4k; ++f) {
-    // ---- overlap-save assemble (Process.cpp:498-522): [previous 2048 | new 2048]
+    // ---- overlap-save assemble (Process.cpp:498-522): [previous N/2 | new N/2]
     const float4 *prev = reinterpret_cast<const float4 *>(st + kStOverlap);
     const float4 *mid = reinterpret_cast<const float4 *>(a.mid + ((size_t)ch * a.nframes4k + f) * (2 * D));
     float4 *A4 = reinterpret_cast<float4 *>(smem);
     __syncthreads();  // the previous frame's pass 3 is done with the array
 #pragma unroll
-    for (int i = wv; i < 16; i += 4) {
+    for (int i = wv; i < N / 256; i += 4) {
       const float4 p = prev[64 * i + lane];
       const float4 n = mid[64 * i + lane];
       A4[64 * i + lane] = p;
-      A4[1024 + 64 * i + lane] = n;
+      A4[N / 4 + 64 * i + lane] = n;
       reinterpret_cast<float4 *>(st + kStOverlap)[64 * i + lane] = n;  // next frame's "previous"
     }
     __syncthreads();
@@ -1657,25 +1680,25 @@ __global__ __launch_bounds__(256) void fastconv4096_kernel(const RxArgs a) {
 #pragma unroll 1
     for (int r = wv; r < 8; r += 4) {
       const int k = lane + 64 * r;
-      cf v[8];
+      cf v[R];
 #pragma unroll
-      for (int p = 0; p < 8; ++p) v[p] = A[k + 512 * p];
-      dft8<false>(v);
+      for (int p = 0; p < R; ++p) v[p] = A[k + 512 * p];
+      dft_r<R, false>(v);
 #pragma unroll
-      for (int q = 1; q < 8; ++q) v[q] = cmul(v[q], tw4k[512 * (q - 1) + k]);
+      for (int q = 1; q < R; ++q) v[q] = cmul(v[q], twN[512 * (q - 1) + k]);
 #pragma unroll
-      for (int q = 0; q < 8; ++q) A[k + 512 * q] = v[q];
+      for (int q = 0; q < R; ++q) A[k + 512 * q] = v[q];
     }
     __syncthreads();
-    // ---- pass 2: 512-point FFT, mask (pre-scaled by 1/4096), inverse 512-point FFT, per q
+    // ---- pass 2: 512-point FFT, mask (pre-scaled by 1/N), inverse 512-point FFT, per q
 #pragma unroll 1
-    for (int q = wv; q < 8; q += 4) {
+    for (int q = wv; q < R; q += 4) {
       cf v[8];
 #pragma unroll
       for (int r = 0; r < 8; ++r) v[r] = A[512 * q + lane + 64 * r];
       fft512<false>(v, tw1, tw2, xbuf, lane);
 #pragma unroll
-      for (int r = 0; r < 8; ++r) v[r] = cmul(v[r], mask4k[512 * q + lane + 64 * r]);
+      for (int r = 0; r < 8; ++r) v[r] = cmul(v[r], maskN[512 * q + lane + 64 * r]);
       fft512<true>(v, tw1, tw2, xbuf, lane);
 #pragma unroll
       for (int r = 0; r < 8; ++r) A[512 * q + lane + 64 * r] = v[r];
@@ -1686,14 +1709,14 @@ __global__ __launch_bounds__(256) void fastconv4096_kernel(const RxArgs a) {
 #pragma unroll 1
     for (int r = wv; r < 8; r += 4) {
       const int k = lane + 64 * r;
-      cf v[8];
+      cf v[R];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) v[q] = A[k + 512 * q];
+      for (int q = 0; q < R; ++q) v[q] = A[k + 512 * q];
 #pragma unroll
-      for (int q = 1; q < 8; ++q) v[q] = cmulc(v[q], tw4k[512 * (q - 1) + k]);
-      dft8<true>(v);
+      for (int q = 1; q < R; ++q) v[q] = cmulc(v[q], twN[512 * (q - 1) + k]);
+      dft_r<R, true>(v);
 #pragma unroll
-      for (int p = 4; p < 8; ++p) au[k + 512 * (p - 4)] = fixed_gain * v[p].x;
+      for (int p = R / 2; p < R; ++p) au[k + 512 * (p - R / 2)] = fixed_gain * v[p].x;
     }
   }
 }
@@ -1734,13 +1757,18 @@ static hipError_t launch512(const RxArgs &a, hipStream_t s, bool debug) {
   return hipGetLastError();
 }
 
-// FFT_LENGTH 4096: front half (8 segments per frame) -> 4096-point fast convolution -> back half
-static hipError_t launch4096(const RxArgs &a, hipStream_t s) {
+// FFT_LENGTH 512 R (R = 2, 4, 8): front half (R segments per frame) -> N-point fast convolution -> back half
+static hipError_t launch_long(const RxArgs &a, hipStream_t s) {
   const int grid = (a.nchan + 3) / 4;
   hipLaunchKernelGGL((rx512_kernel<kModeSsb, false, 1, false>), dim3(grid), dim3(256), 40960, s, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(fastconv4096_kernel, dim3(a.nchan), dim3(256), kFcLdsFloats * sizeof(float), s, a);
+  if (a.seg == 8)
+    hipLaunchKernelGGL(fastconv_kernel<8>, dim3(a.nchan), dim3(256), fc_lds_floats(8) * sizeof(float), s, a);
+  else if (a.seg == 4)
+    hipLaunchKernelGGL(fastconv_kernel<4>, dim3(a.nchan), dim3(256), fc_lds_floats(4) * sizeof(float), s, a);
+  else
+    hipLaunchKernelGGL(fastconv_kernel<2>, dim3(a.nchan), dim3(256), fc_lds_floats(2) * sizeof(float), s, a);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL((rx512_kernel<kModeSsb, false, 2, false>), dim3(grid), dim3(256), 40960, s, a);
@@ -1749,9 +1777,10 @@ static hipError_t launch4096(const RxArgs &a, hipStream_t s) {
 
 hipError_t launch_rx(const RxArgs &a, int fft_length, int mode, hipStream_t s) {
   const bool debug = a.dbg_nco || a.dbg_dec || a.dbg_demod;
-  if (fft_length == 4096) {
+  if (fft_length == 1024 || fft_length == 2048 || fft_length == 4096) {
     if (mode != T41RX_DEMOD_USB && mode != T41RX_DEMOD_LSB) return hipErrorInvalidValue;
-    return launch4096(a, s);
+    if (a.seg * 512 != fft_length) return hipErrorInvalidValue;
+    return launch_long(a, s);
   }
   if (fft_length != 512) return hipErrorInvalidValue;
   switch (mode) {

@@ -37,7 +37,8 @@ struct RxArgs {
   float *mid;              // [nchan][nseg * 256] complex: /8-decimated, level-adjusted I/Q
   float *aud24;            // [nchan][nseg * 256] real: filtered audio @24 kS/s
   const float2 *tab4k;     // tw4096[7][512] | mask4096[8][512] (see kTab4k*)
-  int nframes4k;           // number of 4096-frames (= nframes / 8 for the part kernels)
+  int nframes4k;           // number of long frames (= nframes / seg for the part kernels)
+  int seg;                 // 2048-sample segments per frame = fft_length / 512 (1 for the fused 512 kernel)
   int plain;               // 1: unit band/IQ gains and zero IQ phase correction -> specialised kernel
   int agc;                 // 1: AGCMode != 0 (look-ahead AGC, DSP_Fn.cpp:504-631)
   // the gains of the first stage, by value: a kernel argument is one scalar-load round trip away
@@ -50,12 +51,10 @@ struct RxArgs {
   int q15;                 // 1: I, Q, out point at int16 (q15) samples instead of f32 (Process.cpp:102-111, 936)
 };
 
-// constant table of the 4096-point fast convolution (float2 units):
-//   tw4k  [7][512] : W4096^(k' q), q = 1..7, k' < 512 (forward sign)
-//   mask4k[8][512] : FIR_filter_mask[q + 8 m] / 4096 at [q][m]
-constexpr int kTab4kTw = 0;
-constexpr int kTab4kMask = 7 * 512;
-constexpr int kTab4kEntries = 7 * 512 + 8 * 512;
+// constant table of the N = 512 R point fast convolution (float2 units):
+//   tw  [R-1][512] : W_N^(k' q), q = 1..R-1, k' < 512 (forward sign)
+//   mask[R][512]   : FIR_filter_mask[q + R m] / N at [q][m]
+constexpr int tab_long_entries(int R) { return (R - 1) * 512 + R * 512; }
 
 hipError_t launch_rx(const RxArgs &a, int fft_length, int mode, hipStream_t s);
 

@@ -215,6 +215,23 @@ def test_parity_random_parameter_points(T, kw):
     assert err.max() <= (AM_TOL if mode == 2 else TOL), (kw, err.max(), np.unravel_index(err.argmax(), err.shape))
 
 
+@pytest.mark.parametrize("N", [1024, 2048])
+def test_parity_fft1024_2048(T, N):
+    """the other synthetic FFT lengths of the oracle/designer (FFT_LENGTH is a compile-time
+    constant of the firmware, 512): same three-kernel pipeline as 4096 with 2 / 4 segments per frame"""
+    Lf = 4 * N
+    nch, nfr = 9, 5
+    nco = siggen.nco_grid(nch, seed=N)
+    kw = dict(fft_length=N, mode=1, FLoCut=-2800, FHiCut=-300)
+    I, Q = siggen.make_iq(nch, nfr * Lf, nco, mode=1, seed=N + 1, audio_hz=(500.0, 2400.0))
+    got, _ = gpu_run(T, kw, nco, I, Q)
+    ref = oracle_run(kw, nco, I, Q)
+    err = siggen.block_rel_err(got, ref, Lf)
+    assert err.max() <= TOL, (err.max(), np.unravel_index(err.argmax(), err.shape))
+    split, _ = gpu_run(T, kw, nco, I, Q, split=[0, Lf, 3 * Lf, nfr * Lf])
+    assert np.array_equal(got, split)
+
+
 def test_parity_fft4096(T):
     """BASELINE config 4 (synthetic generalisation): FFT_LENGTH 4096, 16384-sample
     frames, 2049-tap narrow USB filter (400..600 Hz), three-kernel pipeline"""
@@ -400,7 +417,8 @@ def test_argument_errors(T):
     with pytest.raises(T.T41RxError) as e:
         rx.SetNCOFreq(np.full(4, 200000))
     assert e.value.status == _lib.ERR_ARG
-    for unsupported in (dict(AGCMode=1, fft_length=4096, FLoCut=400, FHiCut=600), dict(fft_length=1024),
+    for unsupported in (dict(AGCMode=1, fft_length=4096, FLoCut=400, FHiCut=600),
+                        dict(fft_length=1024, mode=2, FLoCut=-3000, FHiCut=3000),
                         dict(fft_length=4096, mode=3)):
         with pytest.raises(T.T41RxError) as e:
             T.RxChain(4, T.default_params(**unsupported))

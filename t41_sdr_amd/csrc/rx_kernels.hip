@@ -3,8 +3,9 @@
 // One 64-lane wavefront runs one whole ProcessIQData() call (Process.cpp:70-944) for one
 // channel: 2048 complex f32 samples in -> 2048 real f32 samples out, every stage fused, so HBM
 // sees the frame once (16 KiB in + 8 KiB out) plus the ~3 KiB per-channel streaming state.
-// A 256-thread workgroup is four independent waves (no workgroup barriers anywhere); each
-// wave owns a private LDS slice and synchronises with itself only (LDS is in-order per wave).
+// A 256-thread workgroup is four independent waves (one workgroup barrier, for the shared table
+// staging; two more per frame only when the AGC is on); each wave owns a private LDS slice and
+// otherwise synchronises with itself only (LDS is in-order per wave).
 // 16 waves per CU x 256 CUs = 4096 channels in flight = BASELINE config 2's batch.
 //
 // Stage map (reference file:line -> code below):
@@ -18,11 +19,13 @@
 //   overlap-save + 512-pt FFT     Process.cpp:498-535        fft512<false> (radix-8 x3, in regs)
 //   x FIR_filter_mask             Process.cpp:547
 //   inverse FFT                   Process.cpp:595            fft512<true>
-//   AGC off (fixed gain)          DSP_Fn.cpp:494-502
-//   SSB demod                     Process.cpp:616-624,688-694
+//   AGC off (fixed gain) / on     DSP_Fn.cpp:494-502 / 504-631  agc_apply(), agc_chain()
+//   SSB / AM / NFM demod          Process.cpp:616-624,688-694 / 697-707 / 716-727,765-816
 //   interpolate x2 (48 taps)      Process.cpp:917            int1 section
 //   interpolate x4 (32 taps)      Process.cpp:920            int2 section (lane shuffles)
 //   volume                        Process.cpp:929
+//   (q15 samples either side)     Process.cpp:102-111, 936-937  WQ15 kernels
+// FFT_LENGTH 1024 / 2048 / 4096: the same kernel split in two (PART 1 / 2) around fastconv_kernel<R>.
 //
 // No MFMA: FIR taps and FFT butterflies are not dense contractions (BASELINE north_star).
 //

@@ -575,17 +575,38 @@ __device__ __forceinline__ void agc_slow_block(AgcState &st, const AgcConsts &g,
   st = AgcState{fast_backaverage, hang_backaverage, volts, save_volts, state, decay_type, hang_counter};
 }
 
+// Lane masks as plain 64-bit scalars.  Written out by hand because the compiler, given bools,
+// rebuilds them as 0/1 integers in VGPRs every time two of them meet in a select: with these
+// three wrappers a comparison is one VALU instruction with an SGPR-pair result, the logic between
+// masks is scalar ALU, and a select is one v_cndmask.
+typedef unsigned long long lanemask;
+__device__ __forceinline__ lanemask lanes_ge(float a, float b) {
+  lanemask m;
+  asm("v_cmp_ge_f32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b));
+  return m;
+}
+__device__ __forceinline__ lanemask lanes_gt(float a, float b) {
+  lanemask m;
+  asm("v_cmp_gt_f32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b));
+  return m;
+}
+__device__ __forceinline__ float pick(lanemask m, float if_set, float if_clear) {
+  float r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m));
+  return r;
+}
+
 // What the straight-line path needs to know about a lane's state, kept in registers between
 // blocks (recomputed only after a slow block):
-//   stay    : volts += (ring_max - volts) * stay while the lane remains in its decay state
-//             (state 2 = hang: 0, volts rests)
-//   thr     : state 1 leaves fast decay once volts <= save_volts; -inf for the others
-//   in0     : state 0 -- any step that does not attack is a decision, i.e. not for this path
-//   from234 : an attack out of states 2, 3, 4 records save_volts
-//   is3     : state 3 adds its decay step in double (DSP_Fn.cpp:614)
+//   stay  : volts += (ring_max - volts) * stay while the lane remains in its decay state
+//           (state 2 = hang: 0, volts rests)
+//   thr   : state 1 leaves fast decay once volts <= save_volts; -inf for the others
+//   in0   : lanes in state 0 -- any step that does not attack is a decision, i.e. not for this path
+//   pend  : lanes in states 2, 3, 4 that have not attacked yet: their first attack records save_volts
+//   is3   : state 3 adds its decay step in double (DSP_Fn.cpp:614);  is2: hang
 struct AgcLane {
   float stay, thr;
-  bool in0, from234, is3, is2;
+  lanemask in0, pend, is3, is2;
 };
 __device__ __forceinline__ AgcLane agc_lane_of(const AgcState &st, const AgcConsts &g) {
   const int s = st.state;
@@ -595,26 +616,23 @@ __device__ __forceinline__ AgcLane agc_lane_of(const AgcState &st, const AgcCons
   d.stay = (s == 2) ? 0.0f : d.stay;
   d.stay = (s == 3) ? g.decay_mult : d.stay;
   d.thr = (s == 1) ? st.save_volts : -__builtin_inff();
-  d.in0 = s == 0;
-  d.from234 = s >= 2;
-  d.is3 = s == 3;
-  d.is2 = s == 2;
+  d.in0 = __builtin_amdgcn_ballot_w64(s == 0);
+  d.pend = __builtin_amdgcn_ballot_w64(s >= 2);
+  d.is3 = __builtin_amdgcn_ballot_w64(s == 3);
+  d.is2 = __builtin_amdgcn_ballot_w64(s == 2);
   return d;
 }
 
-// The same four steps under the assumption described above; returns false for a lane whose
-// assumption failed somewhere in the block (its results are then meaningless).
+// The same four steps under the assumption described above; a clear bit in the result marks a
+// lane whose assumption failed somewhere in the block (its results are then meaningless).
 // HAS3: some lane is in state 3.
 template <bool HAS3>
-__device__ __forceinline__ bool agc_fast_block(AgcState &st, AgcLane &d, const AgcConsts &g, const float (&rm)[4],
-                                               const float (&pf)[4], const float (&ph)[4], float (&vo)[4]) {
+__device__ __forceinline__ lanemask agc_fast_block(AgcState &st, AgcLane &d, const AgcConsts &g, const float (&rm)[4],
+                                                   const float (&pf)[4], const float (&ph)[4], float (&vo)[4]) {
 #pragma clang fp contract(off)
-  // the hang counter cannot run out inside the block if more than four steps are left.
-  // (bool logic is written with & | ~ on purpose: && || ?: on bools make the compiler build 0/1
-  // integers in VGPRs; this way the masks stay in SGPR pairs and cost no VALU issue)
-  bool ok = !(d.is2 & (st.hang_counter <= 4));
-  bool in0 = d.in0;
-  const bool from234 = d.from234;  // (such a lane starts with in0 = false)
+  // the hang counter cannot run out inside the block if more than four steps are left
+  lanemask ok = ~(d.is2 & __builtin_amdgcn_ballot_w64(st.hang_counter <= 4));
+  lanemask in0 = d.in0, pend = d.pend;
   float volts = st.volts, save_volts = st.save_volts;
   f2 back = f2{st.fast_backaverage, st.hang_backaverage};
   const f2 onem = f2{g.onemfast_backmult, g.onemhang_backmult};
@@ -622,20 +640,21 @@ __device__ __forceinline__ bool agc_fast_block(AgcState &st, AgcLane &d, const A
   asm volatile("" : "+v"(attack_mult), "+v"(min_volts));  // v_cndmask / v_max operands: keep them in VGPRs
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const f2 aged = onem * back;
+    const f2 aged = onem * back;  // :525-526
     back = f2{pf[k], ph[k]} + aged;
     const float ring_max = rm[k];
-    const bool ge = ring_max >= volts;
-    const bool gt = volts > d.thr;
-    ok = ok & (ge | (!in0 & gt));
-    save_volts = (ge & from234 & !in0) ? volts : save_volts;  // the first attack out of 2, 3, 4
-    const float step = (ring_max - volts) * (ge ? attack_mult : d.stay);
+    const lanemask ge = lanes_ge(ring_max, volts);
+    const lanemask gt = lanes_gt(volts, d.thr);
+    ok &= ge | (gt & ~in0);
+    save_volts = pick(ge & pend, volts, save_volts);  // the first attack out of 2, 3, 4
+    pend &= ~ge;
+    in0 |= ge;
+    const float step = (ring_max - volts) * pick(ge, attack_mult, d.stay);
     float next = volts + step;
     if (HAS3) {
       const float next3 = (float)((double)volts + (double)step * .05);
-      next = (ge | !d.is3) ? next : next3;
+      next = pick(d.is3 & ~ge, next3, next);
     }
-    in0 = in0 | ge;
     asm("v_max_f32 %0, %1, %2" : "=v"(volts) : "v"(next), "v"(min_volts));  // :629 (no NaNs here)
     vo[k] = volts;
   }
@@ -643,10 +662,10 @@ __device__ __forceinline__ bool agc_fast_block(AgcState &st, AgcLane &d, const A
   st.hang_backaverage = back.y;
   st.volts = volts;
   st.save_volts = save_volts;
-  st.state = in0 ? 0 : st.state;
+  st.state = __float_as_int(pick(in0, __int_as_float(0), __int_as_float(st.state)));
   const int hc = st.hang_counter - 4;
   st.hang_counter = hc > 0 ? hc : 0;
-  d.from234 = from234 & !in0;
+  d.pend = pend;
   d.in0 = in0;
   return ok;
 }
@@ -681,12 +700,12 @@ __device__ __forceinline__ void agc_chain(float *sl, CoefPtr cf0, int lane STAMP
     float vo[4];
     AgcState t = st;
     AgcLane dt = d;
-    bool ok;
-    if (__builtin_amdgcn_ballot_w64(d.is3 && !d.in0) != 0)
+    lanemask ok;
+    if ((d.is3 & ~d.in0) != 0)
       ok = agc_fast_block<true>(t, dt, g, rm, pf, ph, vo);
     else
       ok = agc_fast_block<false>(t, dt, g, rm, pf, ph, vo);
-    if (__builtin_amdgcn_ballot_w64(!ok) != 0) {  // some lane changes state other than by an attack
+    if (~ok != 0) {  // some lane changes state other than by an attack
       STAMP(24);  // chain: fast blocks
       t = st;
       agc_slow_block(t, g, rm, pf, ph, vo);

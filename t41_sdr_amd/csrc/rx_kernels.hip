@@ -707,8 +707,12 @@ __device__ __forceinline__ void agc_chain(float *sl, CoefPtr cf0, int lane STAMP
       ok = agc_fast_block<false>(t, dt, g, rm, pf, ph, vo);
     if (~ok != 0) {  // some lane changes state other than by an attack
       STAMP(24);  // chain: fast blocks
-      t = st;
-      agc_slow_block(t, g, rm, pf, ph, vo);
+      // only those lanes redo the block (the others' results stand): the lanes that share a
+      // channel take the same branches, so the switch runs without divergence among them
+      if (((~ok >> lane) & 1ull) != 0) {
+        t = st;
+        agc_slow_block(t, g, rm, pf, ph, vo);
+      }
       dt = agc_lane_of(t, g);
       STAMP(25);  // chain: slow blocks
 #ifdef T41RX_STAMP

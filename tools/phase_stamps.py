@@ -31,6 +31,12 @@ def main():
     g = torch.Generator(device="cuda").manual_seed(0)
     I = 0.2 * torch.randn(nch, L, generator=g, device="cuda")
     Q = 0.2 * torch.randn(nch, L, generator=g, device="cuda")
+    if os.environ.get("T41RX_STAMP_SIGNAL") == "bench" and fft == 512:  # bench.py's tones + noise instead of noise
+        import bench
+        Is, Qs = bench.synth_ring(nch, np.full(nch, 5000), 4, torch.device("cuda"), seed=1)
+        for k in range(3):
+            rx.ProcessIQData(Is[k], Qs[k])
+        I, Q = Is[3], Qs[3]
     buf = torch.zeros(nch * D + 2 * nch * 64, device="cuda")  # demod tap | uint64 stamps
     rx.set_debug_taps(None, None, buf)
     for _ in range(3):  # steady state (no start-up transient), warm caches

@@ -121,12 +121,13 @@ def cpu_baseline(Is, Qs, nco_hz, params_kw):
     }
 
 
-def load_traffic():
-    """HBM bytes per launch from committed rocprofv3 PMC passes (profiles/), or None."""
+def load_traffic(workload):
+    """HBM bytes per launch of this workload's kernel from committed rocprofv3 PMC passes
+    (profiles/hbm_traffic.json), or None."""
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     try:
         with open(path) as f:
-            return json.load(f).get("bytes_per_launch")
+            return json.load(f)["workloads"][workload]["bytes_per_launch"]
     except Exception:
         return None
 
@@ -246,7 +247,7 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": load_traffic() if args.workload == "ssb" else None,
+            "traffic": load_traffic(args.workload),
             "kernel": "rx512_kernel" if FFT_LENGTH == 512 else "rx512_kernel<front> + fastconv4096_kernel + rx512_kernel<back>",
             "kernel_ms": round(kernel_ms, 5),
             "algorithmic_bytes_per_launch": int(bytes_per_sample * samples_per_step),

@@ -11,6 +11,6 @@ cd /tmp
 i=0
 for CNT in "$@"; do
   i=$((i+1))
-  rocprofv3 --pmc $CNT --output-format csv -d $OUT/pass$i -o pmc -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/pass$i.log 2>&1 || { echo "pass $i failed"; tail -5 $OUT/pass$i.log; }
+  rocprofv3 --pmc $CNT --output-format csv -d $OUT/pass$i -o pmc -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline ${T41RX_PROF_ARGS} > $OUT/pass$i.log 2>&1 || { echo "pass $i failed"; tail -5 $OUT/pass$i.log; }
 done
 python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py $OUT | tee $OUT/summary.txt

@@ -166,6 +166,18 @@ int    t41rx_set_state(t41rx_ctx *ctx, const void *host_buf, size_t bytes);
  *   demod    : [n_channels][n_frames*fft_length/2] audio @24 kS/s before interpolation */
 int t41rx_set_debug_taps(t41rx_ctx *ctx, float *d_post_nco, float *d_dec, float *d_demod);
 
+/* ---- the path's display by-product: the audio spectrum and the S-meter's input ----
+ * What ProcessIQData() leaves behind when updateDisplayFlag == 1 (Process.cpp:550-570; NFM:
+ * :790-805): audioSpectBuffer[1023 - k] = iFFT_buffer[k]^2 over the 1024 floats of the masked
+ * spectrum (squares of the individual re / im values, reversed), arm_max_f32 of it, and the
+ * running average the S-meter reads (Display.cpp:980-985).  Device pointers, both NULL = off
+ * (the default).  While set, every processed frame writes
+ *   d_spect : [n_channels][n_frames][1024]  audioSpectBuffer
+ *   d_max   : [n_channels][n_frames][3]     audioMaxSquared, (float)AudioMaxIndex, audioMaxSquaredAve
+ * and updates the per-channel audioMaxSquaredAve.  The pixel mapping (audioYPixel) is display
+ * code and stays with the caller.  fft_length 512, f32 entry points only. */
+int t41rx_set_audio_spectrum(t41rx_ctx *ctx, float *d_spect, float *d_max);
+
 #ifdef __cplusplus
 }
 #endif

@@ -480,6 +480,10 @@ struct t41o_channel {
   float *FFT_buffer, *iFFT_buffer;
   /* taps */
   float *tap_ncoI, *tap_ncoQ, *tap_decI, *tap_decQ, *tap_ifft, *tap_demod, *tap_volts;
+  /* Process.cpp:550-570: audioSpectBuffer, audioMaxSquared, AudioMaxIndex, audioMaxSquaredAve */
+  float audioSpectBuffer[1024];
+  float audioMaxSquared, audioMaxSquaredAve;
+  uint32_t AudioMaxIndex;
 };
 
 static float *fzalloc(size_t n) { return (float *)calloc(n, sizeof(float)); }
@@ -579,6 +583,9 @@ void t41o_channel_reset(t41o_channel *ch) {
   ch->agc_out_index = -1;
   ch->agc_in_index = 0;
   ch->agc_in_index_set = 0;
+  memset(ch->audioSpectBuffer, 0, sizeof(ch->audioSpectBuffer));
+  ch->audioMaxSquared = ch->audioMaxSquaredAve = 0.0f;
+  ch->AudioMaxIndex = 0;
 }
 
 int t41o_channel_tap(const t41o_channel *ch, int which, float *dst, int maxlen) {
@@ -592,6 +599,13 @@ int t41o_channel_tap(const t41o_channel *ch, int which, float *dst, int maxlen) 
     case T41O_TAP_IFFT: src = ch->tap_ifft; n = 2 * ch->N; break;
     case T41O_TAP_DEMOD: src = ch->tap_demod; n = ch->D; break;
     case T41O_TAP_AGC_VOLTS: src = ch->tap_volts; n = ch->D; break;
+    case T41O_TAP_AUDIO_SPECT: src = ch->audioSpectBuffer; n = 1024; break;
+    case T41O_TAP_AUDIO_MAX: {
+      float t[3] = {ch->audioMaxSquared, (float)ch->AudioMaxIndex, ch->audioMaxSquaredAve};
+      int m = maxlen < 3 ? maxlen : 3;
+      memcpy(dst, t, sizeof(float) * (size_t)m);
+      return m;
+    }
     default: return -1;
   }
   if (n > maxlen) n = maxlen;
@@ -833,6 +847,31 @@ static void AGC(t41o_channel *ch, const t41o_params *p, const t41o_coeffs *c, fl
     AGC_on(ch, c->agc, iFFT_buffer, N);
 }
 
+/* arm_max_f32 (CMSIS-DSP, scalar): maximum and the index of its FIRST occurrence */
+static void arm_max(const float *src, uint32_t n, float *result, uint32_t *index) {
+  float out = src[0];
+  uint32_t outIndex = 0;
+  for (uint32_t i = 1; i < n; i++) {
+    if (out < src[i]) {
+      out = src[i];
+      outIndex = i;
+    }
+  }
+  *result = out;
+  *index = outIndex;
+}
+
+/* Process.cpp:550-570 (and :790-805 in the NFM pass) with updateDisplayFlag == 1: the audio
+ * spectrum the display and the S-meter (Display.cpp:980-985) are fed from.  The pixel mapping
+ * (audioYPixel, map(), log10f) is display code and not restated.  The loop bound 1024 is the
+ * firmware's literal (2 * FFT_LENGTH for FFT_LENGTH 512): the squares are of the individual
+ * re / im floats, in reversed order. */
+static void audio_spectrum(t41o_channel *ch, const float *iFFT_buffer) {
+  for (int k = 0; k < 1024; k++) ch->audioSpectBuffer[1023 - k] = (iFFT_buffer[k] * iFFT_buffer[k]);
+  arm_max(ch->audioSpectBuffer, 1024, &ch->audioMaxSquared, &ch->AudioMaxIndex);
+  ch->audioMaxSquaredAve = .5 * ch->audioMaxSquared + .5 * ch->audioMaxSquaredAve;
+}
+
 static void cmplx_mult_cmplx(const float *a, const float *b, float *d, int n) {
   for (int i = 0; i < n; i++) { /* arm_cmplx_mult_cmplx_f32 */
     float ar = a[2 * i], ai = a[2 * i + 1], br = b[2 * i], bi = b[2 * i + 1];
@@ -976,6 +1015,7 @@ int t41o_process_frame(t41o_channel *ch, const t41o_params *p, const t41o_coeffs
     }
     t41o_cfft_f32(FFT_buffer, N, 0);                      /* Process.cpp:535 */
     cmplx_mult_cmplx(FFT_buffer, c->mask, iFFT_buffer, N); /* Process.cpp:547 */
+    audio_spectrum(ch, iFFT_buffer);                       /* Process.cpp:550-570 */
     t41o_cfft_f32(iFFT_buffer, N, 1);                     /* Process.cpp:595 */
     AGC(ch, p, c, iFFT_buffer, N);                        /* Process.cpp:605 */
   }
@@ -1020,6 +1060,7 @@ int t41o_process_frame(t41o_channel *ch, const t41o_params *p, const t41o_coeffs
     }
     t41o_cfft_f32(FFT_buffer, N, 0);
     cmplx_mult_cmplx(FFT_buffer, c->mask, iFFT_buffer, N);
+    audio_spectrum(ch, iFFT_buffer);                      /* Process.cpp:790-805 */
     t41o_cfft_f32(iFFT_buffer, N, 1);
     AGC(ch, p, c, iFFT_buffer, N);                        /* Process.cpp:810 */
     for (int i = 0; i < D; i++) fL[i] = iFFT_buffer[N + (i * 2)];

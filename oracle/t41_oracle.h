@@ -149,7 +149,9 @@ enum {
   T41O_TAP_DEC_Q = 3,
   T41O_TAP_IFFT = 4,       /* 2*fft_length interleaved, after AGC */
   T41O_TAP_DEMOD = 5,      /* fft_length/2 audio before interpolation */
-  T41O_TAP_AGC_VOLTS = 6   /* fft_length/2: `volts` after every sample of the last AGC() call */
+  T41O_TAP_AGC_VOLTS = 6,  /* fft_length/2: `volts` after every sample of the last AGC() call */
+  T41O_TAP_AUDIO_SPECT = 7, /* 1024: audioSpectBuffer of the last frame (Process.cpp:550-553) */
+  T41O_TAP_AUDIO_MAX = 8   /* 3: audioMaxSquared, AudioMaxIndex, audioMaxSquaredAve (Process.cpp:569-570) */
 };
 int t41o_channel_tap(const t41o_channel *ch, int which, float *dst, int maxlen);
 

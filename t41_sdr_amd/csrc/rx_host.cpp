@@ -31,6 +31,7 @@ struct t41rx_ctx {
   float2 *d_tab = nullptr;
   ChanNco *d_nco = nullptr;
   float *dbg_nco = nullptr, *dbg_dec = nullptr, *dbg_demod = nullptr;
+  float *spect = nullptr, *spect_max = nullptr;  // audio-spectrum side output (t41rx_set_audio_spectrum)
   // FFT_LENGTH 4096 pipeline: constant table + scratch between its three kernels
   float2 *d_tab4k = nullptr;
   float *d_mid = nullptr, *d_aud24 = nullptr;
@@ -402,8 +403,8 @@ int t41rx_process_device(t41rx_ctx *ctx, const float *dI, const float *dQ, float
 int t41rx_process_device_q15(t41rx_ctx *ctx, const int16_t *dQ_in_L, const int16_t *dQ_in_R, int16_t *dQ_out_L,
                              int n_frames, void *hip_stream) {
   if (ctx && ctx->params.fft_length != 512) return fail(T41RX_ERR_UNSUPPORTED, "the q15 entry points are built for fft_length 512");
-  if (ctx && (ctx->dbg_nco || ctx->dbg_dec || ctx->dbg_demod))
-    return fail(T41RX_ERR_UNSUPPORTED, "debug taps are not available on the q15 entry points");
+  if (ctx && (ctx->dbg_nco || ctx->dbg_dec || ctx->dbg_demod || ctx->spect))
+    return fail(T41RX_ERR_UNSUPPORTED, "debug taps / the audio spectrum are not available on the q15 entry points");
   return process_device_impl(ctx, reinterpret_cast<const float *>(dQ_in_R), reinterpret_cast<const float *>(dQ_in_L),
                              reinterpret_cast<float *>(dQ_out_L), n_frames, hip_stream, true);
 }
@@ -463,6 +464,8 @@ int process_device_impl(t41rx_ctx *ctx, const float *dI, const float *dQ, float 
   a.dbg_nco = ctx->dbg_nco;
   a.dbg_dec = ctx->dbg_dec;
   a.dbg_demod = ctx->dbg_demod;
+  a.spect = ctx->spect;
+  a.spect_max = ctx->spect_max;
   hipError_t e = launch_rx(a, ctx->params.fft_length, ctx->params.mode, (hipStream_t)hip_stream);
   if (e != hipSuccess) return hip_fail(e, "kernel launch");
   return T41RX_OK;
@@ -554,3 +557,13 @@ int t41rx_set_debug_taps(t41rx_ctx *ctx, float *d_post_nco, float *d_dec, float 
 }
 
 }  // extern "C"
+
+int t41rx_set_audio_spectrum(t41rx_ctx *ctx, float *d_spect, float *d_max) {
+  if (!ctx) return fail(T41RX_ERR_ARG, "null context");
+  if ((d_spect == nullptr) != (d_max == nullptr)) return fail(T41RX_ERR_ARG, "set both pointers or neither");
+  if (d_spect && ctx->params.fft_length != 512) return fail(T41RX_ERR_UNSUPPORTED, "the audio spectrum is built for fft_length 512");
+  if ((reinterpret_cast<uintptr_t>(d_spect) | reinterpret_cast<uintptr_t>(d_max)) & 3u) return fail(T41RX_ERR_ARG, "unaligned pointer");
+  ctx->spect = d_spect;
+  ctx->spect_max = d_max;
+  return T41RX_OK;
+}

@@ -1332,6 +1332,39 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
           fft512<false>(v, tw1, tw2, lds, lane);
   #pragma unroll
           for (int r = 0; r < 8; ++r) v[r] = cmul(v[r], ltab[kLdsTabMask + 64 * r + lane]);
+          if (DEBUG && a.spect) {
+            // ---- audio spectrum side output (Process.cpp:550-570 with updateDisplayFlag == 1):
+            // audioSpectBuffer[1023 - k] = iFFT_buffer[k]^2 over the 1024 floats of the masked
+            // spectrum.  The mask table carries 1/N (the reference applies it in the inverse FFT):
+            // a power of two, so squaring after undoing it is exact.  v[r] = bin lane + 64 r.
+            float *sp = a.spect + ((size_t)ch * a.nframes + f) * 1024;
+            float best = -1.0f;
+            int besti = 0;
+  #pragma unroll
+            for (int r = 0; r < 8; ++r) {
+              const int k = lane + 64 * r;
+              const float re = v[r].x * 512.0f, im = v[r].y * 512.0f;
+              const float e0 = im * im, e1 = re * re;  // buffer indices 1022 - 2k, 1023 - 2k
+              *reinterpret_cast<float2 *>(sp + 1022 - 2 * k) = make_float2(e0, e1);
+              // arm_max_f32: the first occurrence of the maximum = the smallest buffer index
+              if (e1 >= best) { best = e1; besti = 1023 - 2 * k; }
+              if (e0 >= best) { best = e0; besti = 1022 - 2 * k; }
+            }
+  #pragma unroll
+            for (int m = 1; m < 64; m <<= 1) {
+              const float ob = __shfl_xor(best, m, 64);
+              const int oi = __shfl_xor(besti, m, 64);
+              if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+            }
+            if (lane == 0) {
+              float *mx = a.spect_max + ((size_t)ch * a.nframes + f) * 3;
+              const float ave = (float)(.5 * (double)best + .5 * (double)st[kStMisc + kMiscMaxSqAve]);  // :570
+              mx[0] = best;
+              mx[1] = (float)besti;
+              mx[2] = ave;
+              st[kStMisc + kMiscMaxSqAve] = ave;
+            }
+          }
           fft512<true>(v, tw1, tw2, lds, lane);
         }
       }
@@ -1802,7 +1835,7 @@ static hipError_t launch_long(const RxArgs &a, hipStream_t s) {
 }
 
 hipError_t launch_rx(const RxArgs &a, int fft_length, int mode, hipStream_t s) {
-  const bool debug = a.dbg_nco || a.dbg_dec || a.dbg_demod;
+  const bool debug = a.dbg_nco || a.dbg_dec || a.dbg_demod || a.spect;  // side outputs ride on the tap kernels
   if (fft_length == 1024 || fft_length == 2048 || fft_length == 4096) {
     if (mode != T41RX_DEMOD_USB && mode != T41RX_DEMOD_LSB) return hipErrorInvalidValue;
     if (a.seg * 512 != fft_length) return hipErrorInvalidValue;

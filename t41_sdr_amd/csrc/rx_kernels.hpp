@@ -33,6 +33,8 @@ struct RxArgs {
   float *dbg_nco;
   float *dbg_dec;
   float *dbg_demod;
+  float *spect;            // audioSpectBuffer side output [nchan][nframes][1024] (or null)
+  float *spect_max;        // [nchan][nframes][3]: audioMaxSquared, AudioMaxIndex, audioMaxSquaredAve
   // FFT_LENGTH 4096 pipeline scratch (device, owned by the context)
   float *mid;              // [nchan][nseg * 256] complex: /8-decimated, level-adjusted I/Q
   float *aud24;            // [nchan][nseg * 256] real: filtered audio @24 kS/s

@@ -166,6 +166,13 @@ class RxChain:
         check(self._lib.t41rx_set_debug_taps(self._ctx, ptr(post_nco), ptr(dec), ptr(demod)))
         self._taps = (post_nco, dec, demod)  # keep alive
 
+    def set_audio_spectrum(self, spect=None, maxima=None):
+        """the display by-product of the path (Process.cpp:550-570): torch CUDA float32 tensors
+        [n_channels, n_frames, 1024] and [n_channels, n_frames, 3], or None/None to switch it off"""
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+        check(self._lib.t41rx_set_audio_spectrum(self._ctx, ptr(spect), ptr(maxima)))
+        self._spect = (spect, maxima)  # keep alive
+
     def _check_shape(self, si, sq):
         if si != sq or len(si) != 2 or si[0] != self.n_channels or si[1] == 0 or si[1] % self.frame_len:
             raise ValueError("I/Q must be [n_channels=%d, k*frame_len=%d], got %r / %r"

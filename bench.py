@@ -43,6 +43,9 @@ WORKLOADS = {
     "nfm": dict(batch=4096, fft=512, kw=dict(mode=3, FLoCut=200, FHiCut=3000, nfmFilterBW=12000),
                 name="configs[2]: NFM path as the firmware runs it (quadri-correlator + limiter + real overlap-save audio "
                      "filter), 4096 channels x 2048 samples per step"),
+    "am": dict(batch=4096, fft=512, kw=dict(mode=2, FLoCut=-3000, FHiCut=3000),
+               name="AM path (AlphaBetaMag envelope, DC block, biquad low-pass; Process.cpp:697-707), 4096 channels x 2048 "
+                    "samples per step"),
     "ssb_agc": dict(batch=4096, fft=512, kw=dict(mode=0, FLoCut=200, FHiCut=3000, AGCMode=1),
                     name="configs[1] with the firmware's default AGCMode = 1 (look-ahead AGC, DSP_Fn.cpp:504-631) instead of "
                          "the fixed gain: 4096 channels x 2048 samples per step (SURVEY 8f rank 1)"),

@@ -172,6 +172,29 @@ int upload_coeffs(t41rx_ctx *ctx) {
     tab[(size_t)(kTabHp8 + l)] = make_float2((float)std::pow(a1, 8.0 * ((l & 15) + 1)), (float)std::pow(a1, 8.0 * ((l & 31) + 1)));
     tab[(size_t)(kTabHp4 + l)] = make_float2((float)std::pow(a1, 4.0 * ((l & 15) + 1)), (float)std::pow(a1, 4.0 * ((l & 31) + 1)));
   }
+  // AM demodulator (Process.cpp:698-705): carry multipliers of its two wave scans.  DC blocker
+  // w = m + 0.99 w_old: powers of ca^4 in double; biquad_lowpass1 (DF1): powers of the 2x2
+  // transition matrix over one lane's four samples, P1 = M^4, M = [[a1, a2], [1, 0]], in f32.
+  {
+    const double ca = (double)0.99f, a4 = ca * ca * ca * ca;
+    struct M2 { float a, b, c, d; };
+    auto mm = [](M2 x, M2 y) { return M2{x.a * y.a + x.b * y.c, x.a * y.b + x.b * y.d, x.c * y.a + x.d * y.c, x.c * y.b + x.d * y.d}; };
+    const M2 M{v.lp1[3], v.lp1[4], 1.0f, 0.0f};
+    const M2 Mq = mm(M, M), P1 = mm(Mq, Mq);
+    for (int l = 0; l < 64; ++l) {
+      double p15 = a4, p31 = a4;
+      M2 Q15 = P1, Q31 = P1;
+      for (int i = 0; i < (l & 15); ++i) { p15 *= a4; Q15 = mm(Q15, P1); }
+      for (int i = 0; i < (l & 31); ++i) { p31 *= a4; Q31 = mm(Q31, P1); }
+      float2 *e = &tab[(size_t)(kTabAm + 6 * l)];
+      std::memcpy(&e[0], &p15, sizeof(double));
+      std::memcpy(&e[1], &p31, sizeof(double));
+      e[2] = make_float2(Q15.a, Q15.b);
+      e[3] = make_float2(Q15.c, Q15.d);
+      e[4] = make_float2(Q31.a, Q31.b);
+      e[5] = make_float2(Q31.c, Q31.d);
+    }
+  }
   HIP_TRY(hipMemcpy(ctx->d_tab, tab.data(), sizeof(float2) * tab.size(), hipMemcpyHostToDevice));
   return T41RX_OK;
 }

@@ -1416,9 +1416,9 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
         double B = wl[3];
         {
           const double a4 = ca * ca * ca * ca, a8 = a4 * a4, a16 = a8 * a8, a32 = a16 * a16;
-          double p15 = a4, p31 = a4;  // ca^(4 ((lane&15)+1)), ca^(4 ((lane&31)+1))
-          for (int i = 0; i < (lane & 15); ++i) p15 *= a4;
-          for (int i = 0; i < (lane & 31); ++i) p31 *= a4;
+          // ca^(4 ((lane&15)+1)), ca^(4 ((lane&31)+1)): per-lane constants from the table
+          const double2 pw = *reinterpret_cast<const double2 *>(tab + kTabAm + 6 * lane);
+          const double p15 = pw.x, p31 = pw.y;
           B = fma(a4, dpp_d<kDppRowShr1, 0xf, true>(B), B);
           B = fma(a8, dpp_d<kDppRowShr2, 0xf, true>(B), B);
           B = fma(a16, dpp_d<kDppRowShr4, 0xf, true>(B), B);
@@ -1469,9 +1469,10 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
           const M2 M{a1, a2, 1.0f, 0.0f};
           const M2 Mq = mm(M, M);
           const M2 P1 = mm(Mq, Mq), P2 = mm(P1, P1), P4 = mm(P2, P2), P8 = mm(P4, P4);
-          M2 Q15 = P1, Q31 = P1;
-          for (int i = 0; i < (lane & 15); ++i) Q15 = mm(Q15, P1);
-          for (int i = 0; i < (lane & 31); ++i) Q31 = mm(Q31, P1);
+          // (M^4)^((lane&15)+1), (M^4)^((lane&31)+1): per-lane constants from the table
+          const float4 q15t = *reinterpret_cast<const float4 *>(tab + kTabAm + 6 * lane + 2);
+          const float4 q31t = *reinterpret_cast<const float4 *>(tab + kTabAm + 6 * lane + 4);
+          const M2 Q15{q15t.x, q15t.y, q15t.z, q15t.w}, Q31{q31t.x, q31t.y, q31t.z, q31t.w};
           auto step = [&](M2 P, float o1, float o2) {
             s1 = s1 + P.a * o1 + P.b * o2;
             s2 = s2 + P.c * o1 + P.d * o2;

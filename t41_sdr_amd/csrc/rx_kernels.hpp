@@ -18,7 +18,12 @@ constexpr int kTabTw2 = kTabTw1 + 7 * 64;
 constexpr int kTabSinCos = kTabTw2 + 7 * 64;
 constexpr int kTabHp8 = kTabSinCos + 256;
 constexpr int kTabHp4 = kTabHp8 + 64;
-constexpr int kTabEntries512 = kTabHp4 + 64;
+//   am[64][6]     : per-lane constants of the AM demodulator's two wave scans (chunks of 4 samples
+//                   per lane): the DC blocker's 0.99^(4((l&15)+1)) and 0.99^(4((l&31)+1)) as doubles
+//                   (2 float2), and the biquad's transition-matrix powers (M^4)^((l&15)+1),
+//                   (M^4)^((l&31)+1) as 2 x 2 float2 each
+constexpr int kTabAm = kTabHp4 + 64;
+constexpr int kTabEntries512 = kTabAm + 64 * 6;
 
 struct RxArgs {
   const float *__restrict__ I;

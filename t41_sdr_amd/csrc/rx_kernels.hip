@@ -1675,8 +1675,13 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
 // separate the passes.  (One wave per channel left a CU with 4 latency-bound waves: 28.5 us for
 // 1024 channels; four per channel: 3 workgroups = 12 waves per CU.)
 // ------------------------------------------------------------------------------------------
-constexpr int kFcXbufFloats = 8 * kFftRow * 2;  // fft512 exchange scratch, one per wave
-constexpr int fc_lds_floats(int R) { return 2 * 512 * R + 4 * kFcXbufFloats; }
+// The working array is R rows of 512 complex; a row is padded to the size of the fft512 exchange
+// scratch (8 x kFftRow complex = 576), because while a wave holds a row in registers for its
+// 512-point FFTs the row's own LDS is free to be that scratch: no separate scratch buffers,
+// 36 KiB per workgroup at R = 8, four workgroups (16 waves) per CU.
+constexpr int kFcRow = 8 * kFftRow;  // complex units per padded row
+static_assert(kFcRow >= 512, "row padding");
+constexpr int fc_lds_floats(int R) { return 2 * kFcRow * R; }
 
 template <int R, bool INV>
 __device__ __forceinline__ void dft_r(cf (&v)[R]) {
@@ -1707,7 +1712,6 @@ __global__ __launch_bounds__(256) void fastconv_kernel(const RxArgs a) {
   const int ch = blockIdx.x;
   if (ch >= a.nchan) return;
   cf *A = reinterpret_cast<cf *>(smem);
-  float *xbuf = smem + 2 * N + wv * kFcXbufFloats;
   float *st = a.state + (size_t)ch * state_floats(N);
   const cf *twN = reinterpret_cast<const cf *>(a.tab4k);                    // [R-1][512]
   const cf *maskN = reinterpret_cast<const cf *>(a.tab4k) + (R - 1) * 512;  // [R][512]
@@ -1728,11 +1732,13 @@ __global__ __launch_bounds__(256) void fastconv_kernel(const RxArgs a) {
     float4 *A4 = reinterpret_cast<float4 *>(smem);
     __syncthreads();  // the previous frame's pass 3 is done with the array
 #pragma unroll
-    for (int i = wv; i < N / 256; i += 4) {
+    for (int i = wv; i < N / 256; i += 4) {  // float4 = 2 complex; 256 float4 per row
       const float4 p = prev[64 * i + lane];
       const float4 n = mid[64 * i + lane];
-      A4[64 * i + lane] = p;
-      A4[N / 4 + 64 * i + lane] = n;
+      const int e = 64 * i + lane;          // float4 index within a half (N/4 of them)
+      const int rp = e >> 8, rn = (e + N / 4) >> 8;
+      A4[rp * (kFcRow / 2) + (e & 255)] = p;
+      A4[rn * (kFcRow / 2) + ((e + N / 4) & 255)] = n;
       reinterpret_cast<float4 *>(st + kStOverlap)[64 * i + lane] = n;  // next frame's "previous"
     }
     __syncthreads();
@@ -1742,12 +1748,12 @@ __global__ __launch_bounds__(256) void fastconv_kernel(const RxArgs a) {
       const int k = lane + 64 * r;
       cf v[R];
 #pragma unroll
-      for (int p = 0; p < R; ++p) v[p] = A[k + 512 * p];
+      for (int p = 0; p < R; ++p) v[p] = A[k + kFcRow * p];
       dft_r<R, false>(v);
 #pragma unroll
       for (int q = 1; q < R; ++q) v[q] = cmul(v[q], twN[512 * (q - 1) + k]);
 #pragma unroll
-      for (int q = 0; q < R; ++q) A[k + 512 * q] = v[q];
+      for (int q = 0; q < R; ++q) A[k + kFcRow * q] = v[q];
     }
     __syncthreads();
     // ---- pass 2: 512-point FFT, mask (pre-scaled by 1/N), inverse 512-point FFT, per q
@@ -1755,13 +1761,16 @@ __global__ __launch_bounds__(256) void fastconv_kernel(const RxArgs a) {
     for (int q = wv; q < R; q += 4) {
       cf v[8];
 #pragma unroll
-      for (int r = 0; r < 8; ++r) v[r] = A[512 * q + lane + 64 * r];
+      for (int r = 0; r < 8; ++r) v[r] = A[kFcRow * q + lane + 64 * r];
+      float *xbuf = smem + 2 * kFcRow * q;  // the row itself (now in registers) is the exchange scratch
+      wave_sync();
       fft512<false>(v, tw1, tw2, xbuf, lane);
 #pragma unroll
       for (int r = 0; r < 8; ++r) v[r] = cmul(v[r], maskN[512 * q + lane + 64 * r]);
       fft512<true>(v, tw1, tw2, xbuf, lane);
+      wave_sync();
 #pragma unroll
-      for (int r = 0; r < 8; ++r) A[512 * q + lane + 64 * r] = v[r];
+      for (int r = 0; r < 8; ++r) A[kFcRow * q + lane + 64 * r] = v[r];
     }
     __syncthreads();
     // ---- pass 3; AGC off: fixed gain (DSP_Fn.cpp:494-502); SSB: audio = Re of the valid half
@@ -1771,7 +1780,7 @@ __global__ __launch_bounds__(256) void fastconv_kernel(const RxArgs a) {
       const int k = lane + 64 * r;
       cf v[R];
 #pragma unroll
-      for (int q = 0; q < R; ++q) v[q] = A[k + 512 * q];
+      for (int q = 0; q < R; ++q) v[q] = A[k + kFcRow * q];
 #pragma unroll
       for (int q = 1; q < R; ++q) v[q] = cmulc(v[q], twN[512 * (q - 1) + k]);
       dft_r<R, true>(v);

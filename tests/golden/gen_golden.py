@@ -30,6 +30,12 @@ CASES = {
     "usb_agc_long": (dict(mode=0, FLoCut=200, FHiCut=3000, AGCMode=1), [5000, -12350]),
     "am_agc_fast": (dict(mode=2, FLoCut=-3000, FHiCut=3000, AGCMode=4), [1000, 33300]),
     "nfm_agc_med": (dict(mode=3, FLoCut=200, FHiCut=3000, AGCMode=3), [2500, -20000]),
+    # the synthetic FFT lengths: frames of 4 * fft_length samples
+    "lsb_fft1024": (dict(mode=1, FLoCut=-2800, FHiCut=-300, fft_length=1024), [7350, -31000]),
+    "usb_fft4096": (dict(mode=0, FLoCut=400, FHiCut=600, fft_length=4096), [12000]),
+    # side output (Process.cpp:550-570) and the q15 boundary (Process.cpp:102-111, 936): extra arrays, see main()
+    "usb_spectrum": (dict(mode=0, FLoCut=200, FHiCut=3000), [5000, -12350]),
+    "usb_q15": (dict(mode=0, FLoCut=200, FHiCut=3000, audioVolume=100), [5000, -12350]),
 }
 FADE = [(0.3, 2.0), (0.3, 0.05), (0.4, 1.2)]  # AGC cases
 NFRAMES_AGC = 10
@@ -60,7 +66,9 @@ def make_inputs(name, kw, nco):
             x = 0.3 * np.exp(1j * ph) + 0.003 * (rng.standard_normal(n.size) + 1j * rng.standard_normal(n.size))
             I[c], Q[c] = x.real, x.imag
         return I, Q
-    return siggen.make_iq(nch, NFRAMES * L, np.asarray(nco), mode=kw["mode"], seed=seed)
+    Lf = 4 * kw.get("fft_length", 512)
+    band = (450.0, 550.0) if kw.get("FHiCut") == 600 and "fft_length" in kw else (400.0, 2500.0)
+    return siggen.make_iq(nch, NFRAMES * Lf, np.asarray(nco), mode=kw["mode"], seed=seed, audio_hz=band)
 
 
 def main():
@@ -68,9 +76,30 @@ def main():
         I, Q = make_inputs(name, kw, nco)
         p = O.default_params(**kw)
         ob = O.OracleBatch(p, np.asarray(nco, dtype=np.int32))
-        out = ob.process(I, Q)
+        extra = {}
+        if name == "usb_q15":  # the queues' samples: L queue = Q, R queue = I (Process.cpp:107-108)
+            qI = np.clip(np.round(I * 32768.0), -32768, 32767).astype(np.int16)
+            qQ = np.clip(np.round(Q * 32768.0), -32768, 32767).astype(np.int16)
+            extra = dict(Q_in_L=qQ, Q_in_R=qI, Q_out_L=ob.process_q15(qQ, qI))
+            I, Q = qI.astype(np.float32) / np.float32(32768), qQ.astype(np.float32) / np.float32(32768)
+            ob.reset()
+        if name == "usb_spectrum":  # audioSpectBuffer / audioMaxSquared, AudioMaxIndex, audioMaxSquaredAve per frame
+            Lf = ob.frame_len
+            nfr = I.shape[1] // Lf
+            out = np.empty_like(I)
+            sp = np.zeros((len(nco), nfr, 1024), np.float32)
+            mx = np.zeros((len(nco), nfr, 3), np.float32)
+            for f in range(nfr):
+                out[:, f * Lf:(f + 1) * Lf] = ob.process(np.ascontiguousarray(I[:, f * Lf:(f + 1) * Lf]),
+                                                         np.ascontiguousarray(Q[:, f * Lf:(f + 1) * Lf]))
+                for c in range(len(nco)):
+                    sp[c, f] = ob.tap(c, O.TAP_AUDIO_SPECT, 1024)
+                    mx[c, f] = ob.tap(c, O.TAP_AUDIO_MAX, 3)
+            extra = dict(spect=sp, spect_max=mx)
+        else:
+            out = ob.process(I, Q)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), I=I, Q=Q, nco=np.asarray(nco, np.int32), audio=out,
-                            params=np.array(sorted(kw.items()), dtype=object).astype(str))
+                            params=np.array(sorted(kw.items()), dtype=object).astype(str), **extra)
         print(name, out.shape, float(np.abs(out).max()))
 
 

@@ -118,5 +118,18 @@ def test_oracle_reproduces_golden(built, path):
     g = np.load(path, allow_pickle=False)
     kw = {k: (float(v) if "." in v else int(v)) for k, v in g["params"]}
     p = O.default_params(**kw)
-    out = O.OracleBatch(p, g["nco"]).process(g["I"], g["Q"])
+    ob = O.OracleBatch(p, g["nco"])
+    if "spect" in g:  # frame by frame, collecting the side output
+        Lf, nch = ob.frame_len, len(g["nco"])
+        for f in range(g["I"].shape[1] // Lf):
+            out = ob.process(np.ascontiguousarray(g["I"][:, f * Lf:(f + 1) * Lf]), np.ascontiguousarray(g["Q"][:, f * Lf:(f + 1) * Lf]))
+            assert np.array_equal(out, g["audio"][:, f * Lf:(f + 1) * Lf])
+            for c in range(nch):
+                assert np.array_equal(ob.tap(c, O.TAP_AUDIO_SPECT, 1024), g["spect"][c, f])
+                assert np.array_equal(ob.tap(c, O.TAP_AUDIO_MAX, 3), g["spect_max"][c, f])
+        return
+    out = ob.process(g["I"], g["Q"])
     assert np.array_equal(out, g["audio"]), "oracle output changed vs committed golden vector"
+    if "Q_out_L" in g:
+        ob.reset()
+        assert np.array_equal(ob.process_q15(g["Q_in_L"], g["Q_in_R"]), g["Q_out_L"])

@@ -475,6 +475,7 @@ struct t41o_channel {
   int agc_hang_counter, agc_out_index;
   uint32_t agc_in_index;
   int agc_in_index_set;               /* AGCLoadValues(): in_index = attack_buffsize + out_index */
+  float agc_edges[25];                /* test aid: how often state a was followed by state b, [5*a + b] */
   /* working buffers (the reference's globals) */
   float *float_buffer_L, *float_buffer_R, *float_buffer_L_EX, *float_buffer_R_EX;
   float *FFT_buffer, *iFFT_buffer;
@@ -583,6 +584,7 @@ void t41o_channel_reset(t41o_channel *ch) {
   ch->agc_out_index = -1;
   ch->agc_in_index = 0;
   ch->agc_in_index_set = 0;
+  memset(ch->agc_edges, 0, sizeof(ch->agc_edges));
   memset(ch->audioSpectBuffer, 0, sizeof(ch->audioSpectBuffer));
   ch->audioMaxSquared = ch->audioMaxSquaredAve = 0.0f;
   ch->AudioMaxIndex = 0;
@@ -600,6 +602,7 @@ int t41o_channel_tap(const t41o_channel *ch, int which, float *dst, int maxlen) 
     case T41O_TAP_DEMOD: src = ch->tap_demod; n = ch->D; break;
     case T41O_TAP_AGC_VOLTS: src = ch->tap_volts; n = ch->D; break;
     case T41O_TAP_AUDIO_SPECT: src = ch->audioSpectBuffer; n = 1024; break;
+    case T41O_TAP_AGC_EDGES: src = ch->agc_edges; n = 25; break;
     case T41O_TAP_AUDIO_MAX: {
       float t[3] = {ch->audioMaxSquared, (float)ch->AudioMaxIndex, ch->audioMaxSquaredAve};
       int m = maxlen < 3 ? maxlen : 3;
@@ -746,6 +749,7 @@ static void AGC_on(t41o_channel *ch, const float *g, float *iFFT_buffer, int FFT
 
     if (hang_counter > 0) --hang_counter;
 
+    const uint8_t state_before = state;
     switch (state) {
       case 0:
         if (ring_max >= volts) {
@@ -822,6 +826,7 @@ static void AGC_on(t41o_channel *ch, const float *g, float *iFFT_buffer, int FFT
     }
     if (volts < min_volts) volts = min_volts; /* no AGC action is taking place */
     ch->tap_volts[i] = volts;
+    ch->agc_edges[5 * state_before + state] += 1.0f;
 
     mult = (out_target - slope_constant * MIN_D(0.0, log10f_fast(inv_max_input * volts))) / volts;
     iFFT_buffer[FFT_length + 2 * i + 0] = out_sample[0] * mult;

@@ -151,7 +151,8 @@ enum {
   T41O_TAP_DEMOD = 5,      /* fft_length/2 audio before interpolation */
   T41O_TAP_AGC_VOLTS = 6,  /* fft_length/2: `volts` after every sample of the last AGC() call */
   T41O_TAP_AUDIO_SPECT = 7, /* 1024: audioSpectBuffer of the last frame (Process.cpp:550-553) */
-  T41O_TAP_AUDIO_MAX = 8   /* 3: audioMaxSquared, AudioMaxIndex, audioMaxSquaredAve (Process.cpp:569-570) */
+  T41O_TAP_AUDIO_MAX = 8,  /* 3: audioMaxSquared, AudioMaxIndex, audioMaxSquaredAve (Process.cpp:569-570) */
+  T41O_TAP_AGC_EDGES = 9   /* 25: since reset, how often AGC state a was followed by b, [5*a + b] (test aid) */
 };
 int t41o_channel_tap(const t41o_channel *ch, int which, float *dst, int maxlen);
 

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 
 DEMOD_USB, DEMOD_LSB, DEMOD_AM, DEMOD_NFM = 0, 1, 2, 3
-TAP_POST_NCO_I, TAP_POST_NCO_Q, TAP_DEC_I, TAP_DEC_Q, TAP_IFFT, TAP_DEMOD, TAP_AGC_VOLTS, TAP_AUDIO_SPECT, TAP_AUDIO_MAX = range(9)
+TAP_POST_NCO_I, TAP_POST_NCO_Q, TAP_DEC_I, TAP_DEC_Q, TAP_IFFT, TAP_DEMOD, TAP_AGC_VOLTS, TAP_AUDIO_SPECT, TAP_AUDIO_MAX, TAP_AGC_EDGES = range(10)
 AGC_NAMES = ("attack_mult", "decay_mult", "fast_decay_mult", "fast_backmult", "onemfast_backmult",
              "hang_backmult", "onemhang_backmult", "hang_decay_mult", "out_target", "min_volts",
              "slope_constant", "inv_max_input", "hang_level", "pop_ratio", "hang_count", "attack_buffsize")

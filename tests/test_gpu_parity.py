@@ -130,10 +130,15 @@ AGC_CASES = [
     (3, 1, 40, [(0.4, 2.5), (0.3, 0.05), (0.3, 1.6)]),      # med, LSB: attack, fast decay, decay
     (4, 2, 30, [(0.4, 2.0), (0.3, 0.05), (0.3, 1.6)]),      # fast, AM
     (1, 3, 12, [(0.4, 1.0), (0.3, 0.3), (0.3, 1.0)]),       # NFM: AGC acts on the filtered audio
+    # bursts: fast decay ending in hang-decay (1>4), decay (1>3), hang (1>2); with slow-usb these walk all
+    # eleven transitions of the gain law (tests/test_oracle_agc.py: test_agc_scenarios_walk_every_transition)
+    (2, 0, 160, [(0.1, 1.5), (0.05, 0.3), (0.003, 2.5), (0.1, 0.3), (0.003, 2.5), (0.55, 0.3), (0.003, 2.5), (0.191, 0.3)]),
+    (2, 0, 60, [(0.25, 0.6), (0.15, 0.2), (0.006, 2.5), (0.594, 0.06)]),
+    (1, 0, 100, [(0.2, 1.5), (0.4, 0.2), (0.003, 2.5), (0.397, 0.2)]),
 ]
 
 
-@pytest.mark.parametrize("agcmode,mode,nfr,segs", AGC_CASES, ids=["slow-usb", "long-usb", "med-lsb", "fast-am", "long-nfm"])
+@pytest.mark.parametrize("agcmode,mode,nfr,segs", AGC_CASES, ids=["slow-usb", "long-usb", "med-lsb", "fast-am", "long-nfm", "bursts-1to4", "bursts-1to3", "bursts-1to2"])
 def test_parity_agc(T, agcmode, mode, nfr, segs):
     nch = 10
     nco = siggen.nco_grid(nch, seed=5 + agcmode)
@@ -153,6 +158,12 @@ def test_parity_agc(T, agcmode, mode, nfr, segs):
     # the gain-law state itself: `volts` after the last sample (state record: 768 + 200 history floats, word 2)
     st = rx.get_state().view(np.float32).reshape(nch, -1)
     volts_ref = np.array([ob.tap(c, O.TAP_AGC_VOLTS, 256)[-1] for c in range(nch)])
+    # what this case is here for: the state changes its signals drive the gain law through
+    edges = sum(ob.tap(c, O.TAP_AGC_EDGES, 25).reshape(5, 5) for c in range(nch))
+    seen = {(a, b) for a in range(5) for b in range(5) if a != b and edges[a, b] > 0}
+    must = {140: {(0, 1), (0, 2), (0, 3), (1, 0), (2, 0), (2, 4), (3, 0), (4, 0)}, 160: {(1, 4), (1, 2), (1, 3)},
+            60: {(1, 3)}, 100: {(1, 2)}}.get(nfr, set())
+    assert must <= seen, (must - seen)
     assert np.abs(st[:, 768 + 200 + 2] - volts_ref).max() <= 1e-5 * volts_ref.max()
     # frame by frame == one call, bit for bit
     split, _ = gpu_run(T, kw, nco, I, Q, split=[0, L, 5 * L, nfr * L])

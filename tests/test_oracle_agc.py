@@ -71,6 +71,39 @@ def test_oracle_agc_matches_f64_model(built, agcmode, mode, nfr, segs, must_visi
     assert err.max() < 3e-4, (err.max(), int(err.argmax()))
 
 
+# fading / burst scenarios that together walk every transition the gain law has
+EDGE_SCENARIOS = [
+    (2, 140, [(0.15, 2.5), (0.75, 0.05), (0.1, 2.5)]),                                   # 0>1 0>2 0>3 1>0 2>0 2>4 3>0 4>0
+    (2, 160, [(0.1, 1.5), (0.05, 0.3), (0.003, 2.5), (0.1, 0.3), (0.003, 2.5), (0.55, 0.3), (0.003, 2.5), (0.191, 0.3)]),  # 1>4
+    (2, 60, [(0.25, 0.6), (0.15, 0.2), (0.006, 2.5), (0.594, 0.06)]),                    # 1>3
+    (1, 100, [(0.2, 1.5), (0.4, 0.2), (0.003, 2.5), (0.397, 0.2)]),                      # 1>2
+]
+ALL_EDGES = {(0, 1), (0, 2), (0, 3), (1, 0), (1, 2), (1, 3), (1, 4), (2, 0), (2, 4), (3, 0), (4, 0)}
+
+
+def agc_edges(agcmode, nfr, segs, seed=5):
+    nco = [7350]
+    I, Q = siggen.make_iq(1, nfr * L, nco, mode=0, seed=seed, audio_hz=(400.0, 2500.0))
+    I, Q = siggen.fade(I, Q, segs)
+    ob = O.OracleBatch(O.default_params(mode=0, AGCMode=agcmode), nco)
+    out = ob.process(I, Q)
+    e = ob.tap(0, O.TAP_AGC_EDGES, 25).reshape(5, 5)
+    return {(a, b) for a in range(5) for b in range(5) if a != b and e[a, b] > 0}, I, Q, nco, ob, out
+
+
+def test_agc_scenarios_walk_every_transition(built):
+    """DSP_Fn.cpp:545-626 has eleven state changes; the scenarios the parity tests use hit all of them
+    (the GPU's slow path is the only code that takes them, so this is what its tests stand on)"""
+    seen = set()
+    for agcmode, nfr, segs in EDGE_SCENARIOS:
+        edges, I, Q, nco, ob, out = agc_edges(agcmode, nfr, segs)
+        seen |= edges
+        # and on each of them the restatement still agrees with the float64 model
+        ref = M.run(I[0], Q[0], nco[0], O.coeff_arrays(ob.c, 512), mode=0, agc=_agc_dict(ob.c))
+        assert siggen.block_rel_err(out, ref[None], L).max() < 3e-4
+    assert seen == ALL_EDGES, (ALL_EDGES - seen, seen - ALL_EDGES)
+
+
 def test_agc_streaming_split_equals_whole(built):
     nco = [-3000, 12000]
     I, Q = siggen.make_iq(2, 12 * L, nco, mode=0, seed=21)

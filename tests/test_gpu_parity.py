@@ -359,13 +359,16 @@ def test_filter_and_tuning_change_mid_stream(T):
     assert err.max() <= TOL, (err.max(), np.unravel_index(err.argmax(), err.shape))
 
 
-def test_checkpoint_and_reset(T):
+@pytest.mark.parametrize("kw", [dict(), dict(AGCMode=2), dict(mode=2, FLoCut=-3000, FHiCut=3000, AGCMode=1), dict(mode=3)],
+                         ids=["usb", "usb-agc", "am-agc", "nfm"])
+def test_checkpoint_and_reset(T, kw):
     import torch
     nch = 8
     nco = siggen.nco_grid(nch, seed=9)
-    I, Q = siggen.make_iq(nch, 4 * L, nco, seed=10)
+    I, Q = siggen.make_iq(nch, 4 * L, nco, seed=10, mode=kw.get("mode", 0))
+    I, Q = siggen.fade(I, Q, [(0.4, 1.5), (0.6, 0.3)])
     dI, dQ = torch.from_numpy(I).cuda(), torch.from_numpy(Q).cuda()
-    rx = T.RxChain(nch, T.default_params(), NCOFreq=nco)
+    rx = T.RxChain(nch, T.default_params(**kw), NCOFreq=nco)
     a1 = rx.ProcessIQData(dI[:, :2 * L].contiguous(), dQ[:, :2 * L].contiguous())
     snap = rx.get_state()
     a2 = rx.ProcessIQData(dI[:, 2 * L:].contiguous(), dQ[:, 2 * L:].contiguous()).clone()
@@ -376,7 +379,7 @@ def test_checkpoint_and_reset(T):
     b1 = rx.ProcessIQData(dI[:, :2 * L].contiguous(), dQ[:, :2 * L].contiguous())
     assert torch.equal(a1, b1)
     # a restored snapshot also works in a different context
-    rx2 = T.RxChain(nch, T.default_params(), NCOFreq=nco)
+    rx2 = T.RxChain(nch, T.default_params(**kw), NCOFreq=nco)
     rx2.set_state(snap)
     a2c = rx2.ProcessIQData(dI[:, 2 * L:].contiguous(), dQ[:, 2 * L:].contiguous())
     assert torch.equal(a2, a2c)

@@ -290,10 +290,10 @@ int t41rx_create(t41rx_ctx **out, int device_id, int n_channels, const t41rx_par
   if (n_channels <= 0) return fail(T41RX_ERR_ARG, "n_channels must be > 0");
   const char *why = nullptr;
   if (!params_valid(*p, &why)) return fail(T41RX_ERR_ARG, why ? why : "bad params");
-  if (p->AGCMode != 0 && p->fft_length != 512) return fail(T41RX_ERR_UNSUPPORTED, "AGC on is built for fft_length 512 only");
+
   if (!t41rx_supported_fft_length(p->fft_length)) return fail(T41RX_ERR_UNSUPPORTED, "no kernel for this fft_length");
-  if (p->fft_length != 512 && !(p->mode == T41RX_DEMOD_USB || p->mode == T41RX_DEMOD_LSB))
-    return fail(T41RX_ERR_UNSUPPORTED, "fft_length 1024/2048/4096 are built for USB/LSB only");
+  if (p->fft_length != 512 && p->mode == T41RX_DEMOD_NFM)
+    return fail(T41RX_ERR_UNSUPPORTED, "NFM is built for fft_length 512 only");
   int ndev = 0;
   HIP_TRY(hipGetDeviceCount(&ndev));
   if (device_id < 0 || device_id >= ndev) return fail(T41RX_ERR_HIP, "no such HIP device");
@@ -344,9 +344,9 @@ int t41rx_set_params(t41rx_ctx *ctx, const t41rx_params *p) {
   const char *why = nullptr;
   if (!params_valid(*p, &why)) return fail(T41RX_ERR_ARG, why ? why : "bad params");
   if (p->fft_length != ctx->params.fft_length) return fail(T41RX_ERR_ARG, "fft_length cannot change on a live context");
-  if (p->AGCMode != 0 && p->fft_length != 512) return fail(T41RX_ERR_UNSUPPORTED, "AGC on is built for fft_length 512 only");
-  if (p->fft_length != 512 && !(p->mode == T41RX_DEMOD_USB || p->mode == T41RX_DEMOD_LSB))
-    return fail(T41RX_ERR_UNSUPPORTED, "fft_length 1024/2048/4096 are built for USB/LSB only");
+
+  if (p->fft_length != 512 && p->mode == T41RX_DEMOD_NFM)
+    return fail(T41RX_ERR_UNSUPPORTED, "NFM is built for fft_length 512 only");
   std::vector<float> nb(ctx->blob.size());
   int rc = design_blob(*p, nb.data(), nb.size() * sizeof(float));
   if (rc != T41RX_OK) return fail(rc, "coefficient design failed");
@@ -380,7 +380,7 @@ int t41rx_set_coeffs(t41rx_ctx *ctx, const void *blob, size_t blob_bytes) {
   if ((uint32_t)h[0] != kBlobMagic || h[1] != T41RX_ABI_VERSION) return fail(T41RX_ERR_STATE, "bad blob header");
   if (h[2] != ctx->params.fft_length) return fail(T41RX_ERR_STATE, "blob fft_length differs from the context");
   if (h[3] < T41RX_DEMOD_USB || h[3] > T41RX_DEMOD_NFM) return fail(T41RX_ERR_STATE, "bad demodulation mode in blob");
-  if (h[2] != 512 && h[3] > T41RX_DEMOD_LSB) return fail(T41RX_ERR_UNSUPPORTED, "fft_length 1024/2048/4096 are built for USB/LSB only");
+  if (h[2] != 512 && h[3] == T41RX_DEMOD_NFM) return fail(T41RX_ERR_UNSUPPORTED, "NFM is built for fft_length 512 only");
   DeviceGuard g(ctx->device);
   HIP_TRY(hipDeviceSynchronize());
   std::memcpy(ctx->blob.data(), blob, need);
@@ -451,7 +451,7 @@ int process_device_impl(t41rx_ctx *ctx, const float *dI, const float *dQ, float 
     ctx->scratch_frames = 0;
     const size_t per = (size_t)ctx->nchan * (size_t)n_frames * (size_t)(256 * seg);  // fft_length / 2 per frame
     HIP_TRY(hipMalloc((void **)&ctx->d_mid, per * 2 * sizeof(float)));
-    HIP_TRY(hipMalloc((void **)&ctx->d_aud24, per * sizeof(float)));
+    HIP_TRY(hipMalloc((void **)&ctx->d_aud24, per * 2 * sizeof(float)));  // complex when the back kernel demodulates
     ctx->scratch_frames = n_frames;
   }
   RxArgs a{};

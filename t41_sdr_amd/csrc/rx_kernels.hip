@@ -931,7 +931,18 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
     float4 agst = make_float4(0, 0, 0, 0);   // AGC record (delay line + state words), one float4 per lane
     float4 hist1 = make_float4(0, 0, 0, 0);  // x2 interpolator history (lanes 0..5)
     float hist2 = 0.0f;                      // x4 interpolator history (lane i = entry i)
-    if (PART == 2) {
+    cf v[8];  // FFT registers; v[0..3] = previous block, v[4..7] = new block / valid half of the result
+    // back half of the long-FFT pipeline with AM or the AGC on: the fast convolution hands over the
+    // complex valid half (no gain applied) and the AGC / demodulator below run here per segment
+    constexpr bool LONGC = (PART == 2) && (MODE == kModeAm || AGC);
+    if (PART == 2 && LONGC) {
+      const cf *yc = reinterpret_cast<const cf *>(a.aud24) + ((size_t)ch * a.nframes + f) * D;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[4 + j] = yc[lane + 64 * j];
+      if (lane < 6) hist1 = *reinterpret_cast<const float4 *>(st + kStInt1 + 4 * lane);
+      if (lane < 8) hist2 = st[kStInt2 + lane];
+      if (AGC && lane < 52) agst = *reinterpret_cast<const float4 *>(st + st_agc(512 * seg) + 4 * lane);
+    } else if (PART == 2) {
       // back half of the 4096 pipeline: this segment's 256 audio samples come from the
       // fast-convolution kernel
       const float *au = a.aud24 + ((size_t)ch * a.nframes + f) * D;
@@ -1040,7 +1051,6 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
 
       STAMP(15);  // prologue d: NCO/DC state uniformisation + Q's DC-block start state
       cf y2[2][2];  // /8 outputs of this frame: m = 128*round + 2*lane + e
-      cf v[8];      // FFT registers; v[0..3] = previous block, prefetched below
 
   #pragma unroll
       for (int rd = 0; rd < 2; ++rd) {
@@ -1368,14 +1378,15 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
           fft512<true>(v, tw1, tw2, lds, lane);
         }
       }
-
+    }
+    if (PART != 2 || LONGC) {
       // ---- AGC (Process.cpp:605 / :810).  Off: fixed gain on the valid half (DSP_Fn.cpp:494-502).
       // SSB/NFM: audio = Re
       const float fixed_gain = fresh_coef(cf0)->sc[kScFixedGain];
       cf og[4];
       if (AGC) {
         const int left = a.nchan - 4 * (int)blockIdx.x;
-        agc_apply(v, agst, lds, smem, st + st_agc(512), cf0, lane, wv, left < 4 ? left : 4, og STAMP_ARGS);
+        agc_apply(v, agst, lds, smem, st + st_agc(512 * seg), cf0, lane, wv, left < 4 ? left : 4, og STAMP_ARGS);
       }
       if (MODE != kModeAm) {
   #pragma unroll
@@ -1702,8 +1713,10 @@ __device__ __forceinline__ void dft_r(cf (&v)[R]) {
   }
 }
 
-// N = 512 R, R = 2, 4, 8 (FFT_LENGTH 1024, 2048, 4096)
-template <int R>
+// N = 512 R, R = 2, 4, 8 (FFT_LENGTH 1024, 2048, 4096).  CPLX: hand the complex valid half on as it
+// is (AM, AGC on: the back kernel applies the AGC / gain and demodulates), else the SSB audio
+// fixed_gain * Re.
+template <int R, bool CPLX>
 __global__ __launch_bounds__(256) void fastconv_kernel(const RxArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int N = 512 * R, D = N / 2;
@@ -1785,7 +1798,12 @@ __global__ __launch_bounds__(256) void fastconv_kernel(const RxArgs a) {
       for (int q = 1; q < R; ++q) v[q] = cmulc(v[q], twN[512 * (q - 1) + k]);
       dft_r<R, true>(v);
 #pragma unroll
-      for (int p = R / 2; p < R; ++p) au[k + 512 * (p - R / 2)] = fixed_gain * v[p].x;
+      for (int p = R / 2; p < R; ++p) {
+        if (CPLX)
+          reinterpret_cast<cf *>(a.aud24)[((size_t)ch * a.nframes4k + f) * D + k + 512 * (p - R / 2)] = v[p];
+        else
+          au[k + 512 * (p - R / 2)] = fixed_gain * v[p].x;
+      }
     }
   }
 }
@@ -1827,29 +1845,47 @@ static hipError_t launch512(const RxArgs &a, hipStream_t s, bool debug) {
 }
 
 // FFT_LENGTH 512 R (R = 2, 4, 8): front half (R segments per frame) -> N-point fast convolution -> back half
-static hipError_t launch_long(const RxArgs &a, hipStream_t s) {
+static hipError_t launch_long(const RxArgs &a, int mode, hipStream_t s) {
   const int grid = (a.nchan + 3) / 4;
   hipLaunchKernelGGL((rx512_kernel<kModeSsb, false, 1, false>), dim3(grid), dim3(256), 40960, s, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
+  const bool cplx = a.agc || mode == T41RX_DEMOD_AM;
+#define T41RX_FC(Rv)                                                                                             \
+  do {                                                                                                           \
+    if (cplx)                                                                                                    \
+      hipLaunchKernelGGL((fastconv_kernel<Rv, true>), dim3(a.nchan), dim3(256), fc_lds_floats(Rv) * sizeof(float), s, a); \
+    else                                                                                                         \
+      hipLaunchKernelGGL((fastconv_kernel<Rv, false>), dim3(a.nchan), dim3(256), fc_lds_floats(Rv) * sizeof(float), s, a); \
+  } while (0)
   if (a.seg == 8)
-    hipLaunchKernelGGL(fastconv_kernel<8>, dim3(a.nchan), dim3(256), fc_lds_floats(8) * sizeof(float), s, a);
+    T41RX_FC(8);
   else if (a.seg == 4)
-    hipLaunchKernelGGL(fastconv_kernel<4>, dim3(a.nchan), dim3(256), fc_lds_floats(4) * sizeof(float), s, a);
+    T41RX_FC(4);
   else
-    hipLaunchKernelGGL(fastconv_kernel<2>, dim3(a.nchan), dim3(256), fc_lds_floats(2) * sizeof(float), s, a);
+    T41RX_FC(2);
+#undef T41RX_FC
   e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((rx512_kernel<kModeSsb, false, 2, false>), dim3(grid), dim3(256), 40960, s, a);
+  if (mode == T41RX_DEMOD_AM) {
+    if (a.agc)
+      hipLaunchKernelGGL((rx512_kernel<kModeAm, false, 2, false, true>), dim3(grid), dim3(256), 40960, s, a);
+    else
+      hipLaunchKernelGGL((rx512_kernel<kModeAm, false, 2, false, false>), dim3(grid), dim3(256), 40960, s, a);
+  } else if (a.agc) {
+    hipLaunchKernelGGL((rx512_kernel<kModeSsb, false, 2, false, true>), dim3(grid), dim3(256), 40960, s, a);
+  } else {
+    hipLaunchKernelGGL((rx512_kernel<kModeSsb, false, 2, false>), dim3(grid), dim3(256), 40960, s, a);
+  }
   return hipGetLastError();
 }
 
 hipError_t launch_rx(const RxArgs &a, int fft_length, int mode, hipStream_t s) {
   const bool debug = a.dbg_nco || a.dbg_dec || a.dbg_demod || a.spect;  // side outputs ride on the tap kernels
   if (fft_length == 1024 || fft_length == 2048 || fft_length == 4096) {
-    if (mode != T41RX_DEMOD_USB && mode != T41RX_DEMOD_LSB) return hipErrorInvalidValue;
+    if (mode == T41RX_DEMOD_NFM) return hipErrorInvalidValue;
     if (a.seg * 512 != fft_length) return hipErrorInvalidValue;
-    return launch_long(a, s);
+    return launch_long(a, mode, s);
   }
   if (fft_length != 512) return hipErrorInvalidValue;
   switch (mode) {

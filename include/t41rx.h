@@ -83,7 +83,7 @@ int         t41rx_abi_version(void);
 const char *t41rx_strerror(int status);
 const char *t41rx_last_error(void);          /* thread-local detail of the last failing call */
 int         t41rx_supported_fft_length(int fft_length); /* 1 if a kernel exists for it: 512 (everything); 1024,
-                                                            2048, 4096 (USB/LSB/AM, any AGCMode, f32 samples) */
+                                                            2048, 4096 (every mode and AGCMode, f32 samples) */
 
 /* Defaults of gwv.cpp:14-96 / bands[] T41_SDR.ino:145-168 (20 m row: USB, 200..3000 Hz) with
  * AGCMode forced to 0. */

@@ -292,8 +292,7 @@ int t41rx_create(t41rx_ctx **out, int device_id, int n_channels, const t41rx_par
   if (!params_valid(*p, &why)) return fail(T41RX_ERR_ARG, why ? why : "bad params");
 
   if (!t41rx_supported_fft_length(p->fft_length)) return fail(T41RX_ERR_UNSUPPORTED, "no kernel for this fft_length");
-  if (p->fft_length != 512 && p->mode == T41RX_DEMOD_NFM)
-    return fail(T41RX_ERR_UNSUPPORTED, "NFM is built for fft_length 512 only");
+
   int ndev = 0;
   HIP_TRY(hipGetDeviceCount(&ndev));
   if (device_id < 0 || device_id >= ndev) return fail(T41RX_ERR_HIP, "no such HIP device");
@@ -345,8 +344,7 @@ int t41rx_set_params(t41rx_ctx *ctx, const t41rx_params *p) {
   if (!params_valid(*p, &why)) return fail(T41RX_ERR_ARG, why ? why : "bad params");
   if (p->fft_length != ctx->params.fft_length) return fail(T41RX_ERR_ARG, "fft_length cannot change on a live context");
 
-  if (p->fft_length != 512 && p->mode == T41RX_DEMOD_NFM)
-    return fail(T41RX_ERR_UNSUPPORTED, "NFM is built for fft_length 512 only");
+
   std::vector<float> nb(ctx->blob.size());
   int rc = design_blob(*p, nb.data(), nb.size() * sizeof(float));
   if (rc != T41RX_OK) return fail(rc, "coefficient design failed");
@@ -380,7 +378,7 @@ int t41rx_set_coeffs(t41rx_ctx *ctx, const void *blob, size_t blob_bytes) {
   if ((uint32_t)h[0] != kBlobMagic || h[1] != T41RX_ABI_VERSION) return fail(T41RX_ERR_STATE, "bad blob header");
   if (h[2] != ctx->params.fft_length) return fail(T41RX_ERR_STATE, "blob fft_length differs from the context");
   if (h[3] < T41RX_DEMOD_USB || h[3] > T41RX_DEMOD_NFM) return fail(T41RX_ERR_STATE, "bad demodulation mode in blob");
-  if (h[2] != 512 && h[3] == T41RX_DEMOD_NFM) return fail(T41RX_ERR_UNSUPPORTED, "NFM is built for fft_length 512 only");
+
   DeviceGuard g(ctx->device);
   HIP_TRY(hipDeviceSynchronize());
   std::memcpy(ctx->blob.data(), blob, need);

@@ -902,6 +902,7 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
   // requests the NEXT segment's first two sub-blocks while it finishes the current one.
   float4 pI0[2], pI1[2], pQ0[2], pQ1[2];
   // PART 2 (4096 back end, same situation): interpolator histories and the next segment's audio
+  cf nfm_carry = splat(0.0f);  // PART 1, NFM: the previous segment's last complex sample
   float4 hist1c = make_float4(0, 0, 0, 0);
   float hist2c = 0.0f, audn[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #ifdef T41RX_STAMP
@@ -1260,14 +1261,6 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
           }
       }
 
-      if (PART == 1) {  // front half of the 4096 pipeline: hand the 256 new /8 samples to the fast-conv kernel
-        float *mid = a.mid + ((size_t)ch * a.nframes + f) * (2 * D);
-  #pragma unroll
-        for (int rd = 0; rd < 2; ++rd)
-          *reinterpret_cast<float4 *>(mid + 2 * (128 * rd + 2 * lane)) =
-              make_float4(y2[rd][0].x, y2[rd][0].y, y2[rd][1].x, y2[rd][1].y);
-        continue;
-      }
       // ---- NFM (Process.cpp:716-727): quadri-correlator discriminator on the 256 new complex
       // samples, hard limiter, then the demodulated REAL audio goes through the same overlap-save
       // filter with zero imaginary part (Process.cpp:765-816)
@@ -1276,6 +1269,8 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
         constexpr double K = 0.340447550238101026565118445432744920253753662109375;
         const cf *ms = reinterpret_cast<const cf *>(st + kStMisc + kMiscNfmI);
         const cf last = ms[0];  // nfmdemod()'s "last sample", see the quirk note below
+        // long FFT (PART 1): nfmdemod() sees the whole frame of 256 seg samples, this is one segment of it
+        const bool frame_first = (PART == 0) || (f & (seg - 1)) == 0;
         float au[2][2];
   #pragma unroll
         for (int rd = 0; rd < 2; ++rd) {
@@ -1285,18 +1280,19 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
           if (rd == 1 && lane == 0)
             prev0 = cf{__int_as_float(__builtin_amdgcn_readlane(__float_as_int(y2[0][1].x), 63)),
                        __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y2[0][1].y), 63))};
+          if (PART == 1 && rd == 0 && lane == 0) prev0 = nfm_carry;  // the previous segment's last sample
           const cf cur0 = y2[rd][0], cur1 = y2[rd][1];
           // Demod.cpp:229-231: (qnow * ilast - inow * qlast) / (inow^2 + qnow^2)
           float num0 = cur0.y * prev0.x - cur0.x * prev0.y;
           const float den0 = cur0.x * cur0.x + cur0.y * cur0.y;
           const float num1 = cur1.y * cur0.x - cur1.x * cur0.y;
           const float den1 = cur1.x * cur1.x + cur1.y * cur1.y;
-          if (rd == 0 && lane == 0)  // Demod.cpp:224: first sample of the frame uses the difference form
+          if (rd == 0 && lane == 0 && frame_first)  // Demod.cpp:224: first sample of the frame uses the difference form
             num0 = cur0.x * (cur0.y - last.y) - cur0.y * (cur0.x - last.x);
           float a0 = (float)(K * (double)num0 / (double)den0);
           float a1 = (float)(K * (double)num1 / (double)den1);
           // Process.cpp:719-727: limiter, skips sample 0 of the frame
-          if (!(rd == 0 && lane == 0)) {
+          if (!(rd == 0 && lane == 0 && frame_first)) {
             a0 = (1.0f < a0) ? 1.0f : a0;
             a0 = (-1.0f > a0) ? -1.0f : a0;
           }
@@ -1307,12 +1303,28 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
         }
         // Demod.cpp:232-233 keeps floats [input_size-2], [input_size-1] of the interleaved buffer
         // as "last sample": that is complex sample 127 (m = 127: round 0, lane 63, odd), not 255
-        if (lane == 63) *reinterpret_cast<cf *>(st + kStMisc + kMiscNfmI) = y2[0][1];
+        // (frame of 256 seg samples: complex sample 128 seg - 1 = the last one of segment seg/2 - 1)
+        if (PART == 0) {
+          if (lane == 63) *reinterpret_cast<cf *>(st + kStMisc + kMiscNfmI) = y2[0][1];
+        } else {
+          if (lane == 63 && (f & (seg - 1)) == seg / 2 - 1) *reinterpret_cast<cf *>(st + kStMisc + kMiscNfmI) = y2[1][1];
+          nfm_carry = cf{__int_as_float(__builtin_amdgcn_readlane(__float_as_int(y2[1][1].x), 63)),
+                         __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y2[1][1].y), 63))};
+        }
   #pragma unroll
         for (int rd = 0; rd < 2; ++rd)
   #pragma unroll
           for (int e = 0; e < 2; ++e) y2[rd][e] = cf{au[rd][e], 0.0f};
       }
+      if (PART == 1) {  // front half of the 4096 pipeline: hand the 256 new /8 samples to the fast-conv kernel
+        float *mid = a.mid + ((size_t)ch * a.nframes + f) * (2 * D);
+  #pragma unroll
+        for (int rd = 0; rd < 2; ++rd)
+          *reinterpret_cast<float4 *>(mid + 2 * (128 * rd + 2 * lane)) =
+              make_float4(y2[rd][0].x, y2[rd][0].y, y2[rd][1].x, y2[rd][1].y);
+        continue;
+      }
+
 
       // ---- overlap-save assemble (Process.cpp:498-522): v[0..3] = previous block, v[4..7] = new
       {
@@ -1847,7 +1859,10 @@ static hipError_t launch512(const RxArgs &a, hipStream_t s, bool debug) {
 // FFT_LENGTH 512 R (R = 2, 4, 8): front half (R segments per frame) -> N-point fast convolution -> back half
 static hipError_t launch_long(const RxArgs &a, int mode, hipStream_t s) {
   const int grid = (a.nchan + 3) / 4;
-  hipLaunchKernelGGL((rx512_kernel<kModeSsb, false, 1, false>), dim3(grid), dim3(256), 40960, s, a);
+  if (mode == T41RX_DEMOD_NFM)
+    hipLaunchKernelGGL((rx512_kernel<kModeNfm, false, 1, false>), dim3(grid), dim3(256), 40960, s, a);
+  else
+    hipLaunchKernelGGL((rx512_kernel<kModeSsb, false, 1, false>), dim3(grid), dim3(256), 40960, s, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   const bool cplx = a.agc || mode == T41RX_DEMOD_AM;
@@ -1883,7 +1898,6 @@ static hipError_t launch_long(const RxArgs &a, int mode, hipStream_t s) {
 hipError_t launch_rx(const RxArgs &a, int fft_length, int mode, hipStream_t s) {
   const bool debug = a.dbg_nco || a.dbg_dec || a.dbg_demod || a.spect;  // side outputs ride on the tap kernels
   if (fft_length == 1024 || fft_length == 2048 || fft_length == 4096) {
-    if (mode == T41RX_DEMOD_NFM) return hipErrorInvalidValue;
     if (a.seg * 512 != fft_length) return hipErrorInvalidValue;
     return launch_long(a, mode, s);
   }

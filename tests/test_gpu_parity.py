@@ -270,15 +270,21 @@ def test_parity_fft1024_2048(T, N):
     (2048, dict(mode=1, FLoCut=-3000, FHiCut=-200, AGCMode=3)),
     (4096, dict(mode=0, FLoCut=200, FHiCut=3000, AGCMode=1)),
     (2048, dict(mode=2, FLoCut=-3000, FHiCut=3000, AGCMode=4)),
-], ids=["am-1024", "am-4096", "usb-agc-1024", "lsb-agc-2048", "usb-agc-4096", "am-agc-2048"])
-def test_parity_long_fft_am_and_agc(T, N, kw):
-    """AM and the AGC at the synthetic FFT lengths: the fast convolution hands the complex valid half
+    (1024, dict(mode=3, FLoCut=200, FHiCut=3000)),
+    (4096, dict(mode=3, FLoCut=200, FHiCut=3000)),
+    (2048, dict(mode=3, FLoCut=200, FHiCut=3000, AGCMode=2)),
+], ids=["am-1024", "am-4096", "usb-agc-1024", "lsb-agc-2048", "usb-agc-4096", "am-agc-2048", "nfm-1024", "nfm-4096", "nfm-agc-2048"])
+def test_parity_long_fft_am_nfm_agc(T, N, kw):
+    """AM, NFM and the AGC at the synthetic FFT lengths: the fast convolution hands the complex valid half
     to the back kernel, which runs the AGC / demodulator per 256-sample segment"""
     Lf = 4 * N
     nch, nfr = 7, 6
     nco = siggen.nco_grid(nch, seed=N + 3)
     kw = dict(kw, fft_length=N)
-    I, Q = siggen.make_iq(nch, nfr * Lf, nco, mode=kw["mode"], seed=N + 4, audio_hz=(500.0, 2400.0))
+    if kw["mode"] == 3:
+        I, Q = siggen.make_fm(nch, nfr * Lf, nco, seed=N + 4)
+    else:
+        I, Q = siggen.make_iq(nch, nfr * Lf, nco, mode=kw["mode"], seed=N + 4, audio_hz=(500.0, 2400.0))
     I, Q = siggen.fade(I, Q, [(0.5, 2.0), (0.2, 0.1), (0.3, 1.0)])
     got, _ = gpu_run(T, kw, nco, I, Q)
     ref = oracle_run(kw, nco, I, Q)
@@ -477,10 +483,11 @@ def test_argument_errors(T):
     with pytest.raises(T.T41RxError) as e:
         rx.SetNCOFreq(np.full(4, 200000))
     assert e.value.status == _lib.ERR_ARG
-    for unsupported in (dict(fft_length=1024, mode=3), dict(fft_length=4096, mode=3)):
-        with pytest.raises(T.T41RxError) as e:
-            T.RxChain(4, T.default_params(**unsupported))
-        assert e.value.status == _lib.ERR_UNSUPPORTED
+    # what has no kernel answers UNSUPPORTED: the side output and the q15 samples at the long FFT lengths
+    rx4k = T.RxChain(2, T.default_params(fft_length=4096, FLoCut=400, FHiCut=600))
+    with pytest.raises(T.T41RxError) as e:
+        rx4k.set_audio_spectrum(torch.zeros(2, 1, 1024, device="cuda"), torch.zeros(2, 1, 3, device="cuda"))
+    assert e.value.status == _lib.ERR_UNSUPPORTED
     with pytest.raises(T.T41RxError) as e:
         rx.CalcFilters(fft_length=1024)
     assert e.value.status in (_lib.ERR_ARG, _lib.ERR_UNSUPPORTED)

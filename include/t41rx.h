@@ -82,8 +82,7 @@ typedef struct t41rx_ctx t41rx_ctx; /* opaque: coefficient arrays + per-channel 
 int         t41rx_abi_version(void);
 const char *t41rx_strerror(int status);
 const char *t41rx_last_error(void);          /* thread-local detail of the last failing call */
-int         t41rx_supported_fft_length(int fft_length); /* 1 if a kernel exists for it: 512 (everything); 1024,
-                                                            2048, 4096 (every mode and AGCMode, f32 samples) */
+int         t41rx_supported_fft_length(int fft_length); /* 1 for 512, 1024, 2048, 4096 */
 
 /* Defaults of gwv.cpp:14-96 / bands[] T41_SDR.ino:145-168 (20 m row: USB, 200..3000 Hz) with
  * AGCMode forced to 0. */
@@ -148,7 +147,7 @@ int t41rx_process_host(t41rx_ctx *ctx, const float *I, const float *Q, float *au
  *   arm_float_to_q15(float_buffer_L, q15_buffer_LTemp, 2048); Q_out_L.play(...)    Process.cpp:936-937
  * with CMSIS-DSP's conversions (x / 32768; truncating, saturating (q15_t)__SSAT((q31_t)(x * 32768), 16)).
  * Layout [n_channels][n_frames*frame_len] int16, the 16 blocks of 128 of a frame back to back.
- * fft_length 512 only; not available while debug taps are set. */
+ * Not available while debug taps or the audio-spectrum output are set. */
 int t41rx_process_device_q15(t41rx_ctx *ctx, const int16_t *dQ_in_L, const int16_t *dQ_in_R,
                              int16_t *dQ_out_L, int n_frames, void *hip_stream);
 int t41rx_process_host_q15(t41rx_ctx *ctx, const int16_t *Q_in_L, const int16_t *Q_in_R,

@@ -423,7 +423,6 @@ int t41rx_process_device(t41rx_ctx *ctx, const float *dI, const float *dQ, float
 // (Process.cpp:107-108)
 int t41rx_process_device_q15(t41rx_ctx *ctx, const int16_t *dQ_in_L, const int16_t *dQ_in_R, int16_t *dQ_out_L,
                              int n_frames, void *hip_stream) {
-  if (ctx && ctx->params.fft_length != 512) return fail(T41RX_ERR_UNSUPPORTED, "the q15 entry points are built for fft_length 512");
   if (ctx && (ctx->dbg_nco || ctx->dbg_dec || ctx->dbg_demod || ctx->spect))
     return fail(T41RX_ERR_UNSUPPORTED, "debug taps / the audio spectrum are not available on the q15 entry points");
   return process_device_impl(ctx, reinterpret_cast<const float *>(dQ_in_R), reinterpret_cast<const float *>(dQ_in_L),

@@ -979,8 +979,10 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
         }
         tailI = *reinterpret_cast<const float4 *>(gI + (L - 256) + 4 * lane);
       } else {  // 8 samples = 16 bytes per lane and array
-        pI0[0] = ldg_stream(gI + 4 * lane);
-        pQ0[0] = ldg_stream(gQ + 4 * lane);
+        if (!carried) {
+          pI0[0] = ldg_stream(gI + 4 * lane);
+          pQ0[0] = ldg_stream(gQ + 4 * lane);
+        }
         const float2 t = *reinterpret_cast<const float2 *>(gI + (L - 256) / 2 + 2 * lane);
         tailI = make_float4(q15_lo(t.x), q15_hi(t.x), q15_lo(t.y), q15_hi(t.y));
       }
@@ -1017,7 +1019,7 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
           pQ0[1] = ldg_stream(gQ + 512 + 8 * lane);
           pQ1[1] = ldg_stream(gQ + 512 + 8 * lane + 4);
         }
-      } else {
+      } else if (!carried) {
         pI0[1] = ldg_stream(gI + 256 + 4 * lane);
         pQ0[1] = ldg_stream(gQ + 256 + 4 * lane);
       }
@@ -1045,7 +1047,15 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
       // segments, so the I chain runs on across segments and the Q chain starts from the state
       // after the frame's LAST I samples.
       if (PART == 0 || (f & (seg - 1)) == 0) {
-        const float4 tailF = (PART == 0) ? tailI : *reinterpret_cast<const float4 *>(gI + (seg * L - 256) + 4 * lane);
+        float4 tailF = tailI;
+        if (PART != 0) {  // the frame's last 256 I samples are seg segments further on
+          if (!WQ15) {
+            tailF = *reinterpret_cast<const float4 *>(gI + (seg * L - 256) + 4 * lane);
+          } else {
+            const float2 t = *reinterpret_cast<const float2 *>(gI + (seg * L - 256) / 2 + 2 * lane);
+            tailF = make_float4(q15_lo(t.x), q15_hi(t.x), q15_lo(t.y), q15_hi(t.y));
+          }
+        }
         const float x[4] = {tailF.x * g_rf, tailF.y * g_rf, tailF.z * g_rf, tailF.w * g_rf};
         dc2 = f2{(g_rf_i != g_rf) ? -dc_carry : dc_carry, dc_highpass_end_state<4>(x, hp4.x, hp4.y)};
       }
@@ -1091,11 +1101,17 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
             }
           } else if (PART == 1) {  // the next segment's sub-blocks 0 and 1 (same channel: contiguous)
             if (f + 1 < a.nframes) {
-              const int o = L + 512 * (s - 2) + 8 * lane;
-              pI0[h] = ldg_stream(gI + o);
-              pI1[h] = ldg_stream(gI + o + 4);
-              pQ0[h] = ldg_stream(gQ + o);
-              pQ1[h] = ldg_stream(gQ + o + 4);
+              if (!WQ15) {
+                const int o = L + 512 * (s - 2) + 8 * lane;
+                pI0[h] = ldg_stream(gI + o);
+                pI1[h] = ldg_stream(gI + o + 4);
+                pQ0[h] = ldg_stream(gQ + o);
+                pQ1[h] = ldg_stream(gQ + o + 4);
+              } else {
+                const int o = L / 2 + 256 * (s - 2) + 4 * lane;
+                pI0[h] = ldg_stream(gI + o);
+                pQ0[h] = ldg_stream(gQ + o);
+              }
             }
           } else if (s == 3) {  // last sub-block: prefetch the overlap-save "previous" block instead
             const cf *ov = reinterpret_cast<const cf *>(st + kStOverlap);
@@ -1859,10 +1875,16 @@ static hipError_t launch512(const RxArgs &a, hipStream_t s, bool debug) {
 // FFT_LENGTH 512 R (R = 2, 4, 8): front half (R segments per frame) -> N-point fast convolution -> back half
 static hipError_t launch_long(const RxArgs &a, int mode, hipStream_t s) {
   const int grid = (a.nchan + 3) / 4;
-  if (mode == T41RX_DEMOD_NFM)
-    hipLaunchKernelGGL((rx512_kernel<kModeNfm, false, 1, false>), dim3(grid), dim3(256), 40960, s, a);
-  else
+  if (mode == T41RX_DEMOD_NFM) {
+    if (a.q15)
+      hipLaunchKernelGGL((rx512_kernel<kModeNfm, false, 1, false, false, true>), dim3(grid), dim3(256), 40960, s, a);
+    else
+      hipLaunchKernelGGL((rx512_kernel<kModeNfm, false, 1, false>), dim3(grid), dim3(256), 40960, s, a);
+  } else if (a.q15) {
+    hipLaunchKernelGGL((rx512_kernel<kModeSsb, false, 1, false, false, true>), dim3(grid), dim3(256), 40960, s, a);
+  } else {
     hipLaunchKernelGGL((rx512_kernel<kModeSsb, false, 1, false>), dim3(grid), dim3(256), 40960, s, a);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   const bool cplx = a.agc || mode == T41RX_DEMOD_AM;
@@ -1882,16 +1904,24 @@ static hipError_t launch_long(const RxArgs &a, int mode, hipStream_t s) {
 #undef T41RX_FC
   e = hipGetLastError();
   if (e != hipSuccess) return e;
+#define T41RX_BACK(MODEv, AGCv)                                                                                   \
+  do {                                                                                                            \
+    if (a.q15)                                                                                                    \
+      hipLaunchKernelGGL((rx512_kernel<MODEv, false, 2, false, AGCv, true>), dim3(grid), dim3(256), 40960, s, a); \
+    else                                                                                                          \
+      hipLaunchKernelGGL((rx512_kernel<MODEv, false, 2, false, AGCv, false>), dim3(grid), dim3(256), 40960, s, a); \
+  } while (0)
   if (mode == T41RX_DEMOD_AM) {
     if (a.agc)
-      hipLaunchKernelGGL((rx512_kernel<kModeAm, false, 2, false, true>), dim3(grid), dim3(256), 40960, s, a);
+      T41RX_BACK(kModeAm, true);
     else
-      hipLaunchKernelGGL((rx512_kernel<kModeAm, false, 2, false, false>), dim3(grid), dim3(256), 40960, s, a);
+      T41RX_BACK(kModeAm, false);
   } else if (a.agc) {
-    hipLaunchKernelGGL((rx512_kernel<kModeSsb, false, 2, false, true>), dim3(grid), dim3(256), 40960, s, a);
+    T41RX_BACK(kModeSsb, true);
   } else {
-    hipLaunchKernelGGL((rx512_kernel<kModeSsb, false, 2, false>), dim3(grid), dim3(256), 40960, s, a);
+    T41RX_BACK(kModeSsb, false);
   }
+#undef T41RX_BACK
   return hipGetLastError();
 }
 

@@ -10,6 +10,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -36,6 +37,7 @@ struct t41rx_ctx {
   float2 *d_tab4k = nullptr;
   float *d_mid = nullptr, *d_aud24 = nullptr;
   int scratch_frames = 0;
+  int stagger = 0;               // launch tuning: see RxArgs::stagger (env T41RX_STAGGER overrides)
   // staging for t41rx_process_host
   float *d_in_i = nullptr, *d_in_q = nullptr, *d_out = nullptr;
   size_t staging_floats = 0;
@@ -304,6 +306,7 @@ int t41rx_create(t41rx_ctx **out, int device_id, int n_channels, const t41rx_par
   ctx->device = device_id;
   ctx->nchan = n_channels;
   ctx->params = *p;
+  if (const char *e = std::getenv("T41RX_STAGGER")) ctx->stagger = std::atoi(e);
   ctx->blob.assign(blob_floats(p->fft_length), 0.0f);
   ctx->nco_hz.assign((size_t)n_channels, 0);
   int rc = design_blob(*p, ctx->blob.data(), ctx->blob.size() * sizeof(float));
@@ -478,6 +481,7 @@ int process_device_impl(t41rx_ctx *ctx, const float *dI, const float *dQ, float 
     a.plain = ((gi == 1.0f || (iq_on && gi == -1.0f)) && sc[kScBandGain] == 1.0f && (!iq_on || sc[kScIqPhase] == 0.0f)) ? 1 : 0;
   }
   a.q15 = q15 ? 1 : 0;
+  a.stagger = (n_frames >= 4) ? ctx->stagger : 0;  // pays only when a launch runs several frames
   a.agc = ctx->params.AGCMode != 0 ? 1 : 0;
   if (a.agc && (int)blob_view(ctx->blob.data()).agc[kAgcAttackBuffsize] != kAgcDelay)
     return fail(T41RX_ERR_STATE, "coefficient blob carries an AGC look-ahead the kernel is not built for");

@@ -64,6 +64,12 @@ __device__ __forceinline__ void wave_sync() {
 #define T41RX_ABLATE 0
 #endif
 #define T41RX_CUT(n) (T41RX_ABLATE >= (n) && T41RX_ABLATE <= 8)
+// Fused kernel: how many of the next frame's sub-blocks are requested during the current frame
+// (0: none, 1: sub-block 0 + the I tail, 2: sub-blocks 0 and 1 + the I tail).  Each one costs 16
+// registers that stay live through the back end.
+#ifndef T41RX_PF
+#define T41RX_PF 2
+#endif
 // Issue priority falls as a wave advances through its frame (3: loads, mixer, decimators; 2:
 // FFTs and demodulator; 0: interpolators and stores), so the waves sharing a SIMD progress evenly
 // instead of oldest-first, which left each SIMD with one or two latency-bound waves for the last
@@ -205,6 +211,52 @@ __device__ __forceinline__ void fft512(cf (&v)[8], const cf (&tw1)[7], const cf 
   dft8<INV>(v);
 }
 
+// The same with the twiddles read from the workgroup's LDS tables right where they are used
+// (tw1l: this lane's column of tw1[7][64]; tw2l: its column of the compacted tw2[7][8]) instead of
+// held in 28 registers across both transforms: the fused kernel carries the next frame's input
+// prefetch through its back end and has no registers to spare.  `mid()` runs between the first and
+// the second stage (the fused kernel requests the filter mask there).
+template <bool INV, typename MID>
+__device__ __forceinline__ void fft512_ldstw(cf (&v)[8], const cf *tw1l, const cf *tw2l, float *__restrict__ xbuf,
+                                             int lane, MID mid) {
+  cf *xb = reinterpret_cast<cf *>(xbuf);
+  dft8<INV>(v);
+#pragma unroll
+  for (int q = 1; q < 8; ++q) {
+    const cf w = tw1l[64 * (q - 1)];
+    v[q] = INV ? cmulc(v[q], w) : cmul(v[q], w);
+  }
+  wave_sync();
+#pragma unroll
+  for (int q = 0; q < 8; ++q) xb[q * kFftRow + lane] = v[q];
+  wave_sync();
+  mid();
+  {
+    const int l1 = lane & 7, q = lane >> 3;
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) v[k2] = xb[q * kFftRow + l1 + 8 * k2];
+  }
+  dft8<INV>(v);
+#pragma unroll
+  for (int q = 1; q < 8; ++q) {
+    const cf w = tw2l[8 * (q - 1)];
+    v[q] = INV ? cmulc(v[q], w) : cmul(v[q], w);
+  }
+  wave_sync();
+  {
+    const int l1 = lane & 7, q = lane >> 3;
+#pragma unroll
+    for (int q2 = 0; q2 < 8; ++q2) xb[q2 * kFftRow + q + 8 * l1] = v[q2];
+  }
+  wave_sync();
+  {
+    const int q = lane & 7, q2 = lane >> 3;
+#pragma unroll
+    for (int l1 = 0; l1 < 8; ++l1) v[l1] = xb[q2 * kFftRow + q + 8 * l1];
+  }
+  dft8<INV>(v);
+}
+
 // ------------------------------------------------------------------------------------------
 // DC high-pass (HP_DC_Filter_Coeffs2, FIR.cpp:87-89): y = b0 x + d; d' = b1 x + a1 y  (b2=a2=0)
 // ------------------------------------------------------------------------------------------
@@ -328,7 +380,7 @@ constexpr int kLdsTabMask = 0, kLdsTabTw1 = 512, kLdsTabTw2 = 512 + 448;  // flo
 constexpr int kLdsTabFloats = 2 * (512 + 448 + 56);                          // 2032 floats
 constexpr int kXFloats = 1352;  // 2 * (xpad(539) + 1) = 1348, rounded to 16 B
 constexpr int kY1Floats = 608;  // 304 complex
-constexpr int kX = 0, kY1 = kXFloats;
+// (offsets of X, Y1 and the back-end scratch: Geo<PART> below)
 // 2052 floats = 8208 B: X + Y1 (1960) rounded up so the whole slice can double as the 2048-float
 // output transposition buffer; tables + 4 slices = exactly the 40 KiB the launch requests
 constexpr int kLdsFloatsPerWave = 2052;
@@ -456,14 +508,24 @@ __device__ __forceinline__ NcoPtr fresh_nco(NcoPtr p) {
 // decay moves volts by a few ulps per sample, so any reassociation drifts by percents over a
 // second) -- runs as a scalar chain, one LANE per channel: lanes 0..3 of the workgroup's first
 // wave take the four channels of the workgroup between two workgroup barriers.
-// LDS (floats, in the wave's slice):
-constexpr int kAgZ = 0;     // (re, im)[356]: [0..99] the last 100 inputs, [100 + i] this frame's input i
-constexpr int kAgA = 712;   // |z|[356], same indexing
-constexpr int kAgG = 1068;  // max of every aligned group of four |z| (89 used)
-constexpr int kAgR = 1160;  // ring_max[256]; the chain replaces it by volts[256]
-constexpr int kAgP = 1416;  // (fast_backmult, hang_backmult) * abs_out_sample, [256] pairs
-constexpr int kAgS = 1928;  // the 8 state words (rx_internal.hpp: kAgcSt*)
-static_assert(kAgS + kAgcScalars <= kLdsFloatsPerWave, "AGC scratch must fit the wave slice");
+// LDS (floats, in the wave's slice).  Two layouts:
+//  * AgcLds<false> (the long-FFT back kernel, 4-wave workgroups): the scratch starts at the slice.
+//  * AgcLds<true>  (the fused FFT_LENGTH 512 kernel, whose delay lines, overlap block and x2
+//    history stay in LDS across frames, see Geo<0>): the scratch avoids them -- ring_max / volts
+//    reuse the |z| array (every read of |z| precedes the first write of ring_max in program order,
+//    and LDS executes a wave's instructions in order), the (b x) pairs sit in the free part of Y1.
+template <bool RESIDENT>
+struct AgcLds {
+  static constexpr int Z = RESIDENT ? 68 : 0;        // (re, im)[356]: [0..99] the last 100 inputs, [100 + i] this frame's input i
+  static constexpr int A = Z + 712;                  // |z|[356], same indexing
+  static constexpr int G = A + 356;                  // max of every aligned group of four |z| (89 used)
+  static constexpr int S = RESIDENT ? G + 92 : 1928; // the 8 state words (rx_internal.hpp: kAgcSt*)
+  static constexpr int R = RESIDENT ? A : 1160;      // ring_max[256]; the chain replaces it by volts[256]
+  static constexpr int P = RESIDENT ? 1348 + 96 : 1416;  // (fast_backmult, hang_backmult) * abs_out_sample, [256] pairs
+  static constexpr int kEnd = RESIDENT ? 1348 + 608 : 1936;
+};
+static_assert(AgcLds<false>::S + kAgcScalars <= kLdsFloatsPerWave, "AGC scratch must fit the wave slice");
+static_assert(AgcLds<true>::S + kAgcScalars <= 1348 && AgcLds<true>::P + 512 <= AgcLds<true>::kEnd, "AGC scratch vs resident state");
 static_assert(kAgcDelay == 97 && kAgcHist == 100, "window arithmetic below is written for 97 / 100");
 #ifndef T41RX_AGC_COOP
 #define T41RX_AGC_COOP 1
@@ -670,7 +732,9 @@ __device__ __forceinline__ lanemask agc_fast_block(AgcState &st, AgcLane &d, con
   return ok;
 }
 
+template <typename AL>
 __device__ __forceinline__ void agc_chain(float *sl, CoefPtr cf0, int lane STAMP_PARAMS) {
+  constexpr int kAgR = AL::R, kAgP = AL::P, kAgS = AL::S;
   const CoefPtr c = fresh_coef(cf0);
   AgcConsts g;
   g.attack_mult = c->agc[kAgcAttackMult];
@@ -730,8 +794,11 @@ __device__ __forceinline__ void agc_chain(float *sl, CoefPtr cf0, int lane STAMP
 // v[4 + j] = inverse FFT output sample i = lane + 64 j (the valid half); agst = this lane's
 // float4 of the channel's AGC record (lanes 0..49 delay line, 50..51 state words).
 // og[k] = AGC output sample 4 lane + k.
-__device__ __forceinline__ void agc_apply(const cf (&v)[8], float4 agst, float *lds, float *smem, float *st_ag,
+// slices: the first wave slice of the workgroup, NW / SLICE: waves per workgroup / floats per slice.
+template <typename AL, int NW, int SLICE>
+__device__ __forceinline__ void agc_apply(const cf (&v)[8], float4 agst, float *lds, float *slices, float *st_ag,
                                           CoefPtr cf0, int lane, int wv, int nvalid, cf (&og)[4] STAMP_PARAMS) {
+  constexpr int kAgZ = AL::Z, kAgA = AL::A, kAgG = AL::G, kAgR = AL::R, kAgP = AL::P, kAgS = AL::S;
   wave_sync();
   if (lane < 50) *reinterpret_cast<float4 *>(lds + kAgZ + 4 * lane) = agst;
   else if (lane < 52) *reinterpret_cast<float4 *>(lds + kAgS + 4 * (lane - 50)) = agst;
@@ -780,21 +847,21 @@ __device__ __forceinline__ void agc_apply(const cf (&v)[8], float4 agst, float *
   if (kAgcCoop) {
     __syncthreads();
     STAMP(20);  // AGC: barrier 1
-    // wave 0 runs the chains: the hardware places the first waves of the workgroups sharing a CU
-    // on different SIMDs (HW_ID dump of the -DT41RX_STAMP build), so the four chains of a CU do
-    // not compete for issue slots
+    // wave 0 runs the chains of all the workgroup's channels, one lane per channel (4-wave
+    // workgroups: the hardware places the first waves of the workgroups sharing a CU on different
+    // SIMDs, HW_ID dump of the -DT41RX_STAMP build, so the chains of a CU do not compete for issue slots)
     const int cw = 0;
     // All 64 lanes stay enabled (lane l redoes channel l mod nvalid): measured on MI355X
     // (tools/ubench/exec_mask.hip), VALU instructions of a wave with 16 or fewer active lanes
     // take 3-4x longer than with 32 or more.
     if (wv == cw)
-      agc_chain(smem + kLdsTabFloats + (nvalid == 4 ? (lane & 3) : lane % nvalid) * kLdsFloatsPerWave, cf0, lane STAMP_ARGS);
+      agc_chain<AL>(slices + (nvalid == NW ? (lane & (NW - 1)) : lane % nvalid) * SLICE, cf0, lane STAMP_ARGS);
     STAMP(21);  // AGC: the serial chain (chain wave only)
     __syncthreads();
     STAMP(22);  // AGC: barrier 2 (= waiting for the chain, for the other waves)
   } else {
     wave_sync();
-    agc_chain(lds, cf0, lane STAMP_ARGS);
+    agc_chain<AL>(lds, cf0, lane STAMP_ARGS);
     wave_sync();
   }
   {
@@ -836,16 +903,55 @@ constexpr int kModeSsb = 0, kModeAm = 1, kModeNfm = 2;  // kernel template MODE
 // (Process.cpp:936): a.I / a.Q / a.out then point at int16 samples, same [channel][frame*2048]
 // layout.  The conversions are exact (x / 32768 folds into the RF-gain factor, a power of two)
 // resp. CMSIS' truncating, saturating float -> q15.
+// LDS geometry of rx512_kernel (floats).
+// PART 0 -- the fused FFT_LENGTH 512 chain -- runs as ONE 16-wave workgroup per CU that owns all
+// 160 KiB of LDS: [tw1, tw2 1024 | 16 wave slices of 2496].  A wave keeps its channel's streaming
+// state ON CHIP across the frames of a launch: the /4 and /2 delay lines stay where the history
+// rolls leave them (X[0..68), Y1[0..96)), the overlap-save block and the x2 interpolator history
+// have their own slots (OV, H1), the x4 history and the NCO / DC scalars live in registers.  HBM
+// state is read before the first frame and written after the last.  Everything the back end needs
+// as scratch (FFT exchange, AGC, x2 window, output transposition in two halves) therefore avoids
+// those regions: it lives in X[80 ..) and the free part of Y1.  Only the FFT twiddles are staged in
+// LDS; the filter mask comes from the (L2-resident) constant table per frame: that is what makes
+// the slices fit.
+// PART 1 / 2 -- the two ends of the long-FFT pipeline -- keep 4-wave workgroups, 4 per CU:
+// [mask, tw1, tw2 2032 | 4 slices of 2052], scratch from the start of the slice.
+template <int PART>
+struct Geo {
+  static constexpr bool kResident = (PART == 0);
+  static constexpr int kWaves = kResident ? 16 : 4;
+  static constexpr int kTab = kResident ? 1024 : kLdsTabFloats;
+  static constexpr int kTw1 = kResident ? 0 : kLdsTabTw1;        // float2 units within the tables
+  static constexpr int kTw2 = kResident ? 448 : kLdsTabTw2;
+  static constexpr int kSlice = kResident ? 2496 : kLdsFloatsPerWave;
+  static constexpr int kTotal = kTab + kWaves * kSlice;
+  static constexpr int kX = 0;
+  static constexpr int kXF = kResident ? 1348 : kXFloats;  // 2 * (xpad(539) + 1)
+  static constexpr int kY1 = kXF;
+  static constexpr int kOV = kY1 + kY1Floats;   // resident: overlap-save "previous" block, 256 complex in [j][lane] order
+  static constexpr int kH1 = kOV + 512;         // resident: x2 interpolator history, 24 floats
+  static constexpr int kScr = kResident ? 80 : 0;        // FFT exchange (1152), overlap assembly, output transposition
+  static constexpr int kI1 = kResident ? kY1 + 96 : 0;   // x2 interpolator window: 24 history + 256 new
+};
+static_assert(Geo<0>::kTotal * sizeof(float) == 160 * 1024, "PART 0: one workgroup owns the CU's LDS");
+static_assert(Geo<1>::kTotal * sizeof(float) == 40960, "PART 1/2: four workgroups per CU");
+static_assert(Geo<0>::kH1 + 24 <= Geo<0>::kSlice && Geo<0>::kScr + 8 * kFftRow * 2 <= Geo<0>::kXF &&
+              Geo<0>::kI1 + 284 <= Geo<0>::kOV && Geo<0>::kScr >= 68, "resident LDS layout");
+
 template <int MODE, bool DEBUG, int PART, bool PLAIN, bool AGC = false, bool WQ15 = false>
-__global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+__global__ __launch_bounds__(Geo<PART>::kWaves * 64, 4) void rx512_kernel(const RxArgs a) {
+  typedef Geo<PART> G;
+  constexpr bool KEEP = G::kResident;  // streaming state stays on chip across the frames of a launch
+  constexpr int NW = G::kWaves;
+  constexpr int kX = G::kX, kY1 = G::kY1, kScr = G::kScr, kI1 = G::kI1;
+  __shared__ __attribute__((aligned(16))) float smem[G::kTotal];
   constexpr int L = 2048, D = 256, N = 512;
   // per-channel state record size follows fft_length = 512 * (segments per frame)
   const int seg = (PART == 0) ? 1 : a.seg;
   const size_t state_stride = state_floats(512 * seg);
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int ch = blockIdx.x * 4 + wv;
+  const int ch = blockIdx.x * NW + wv;
 
   // mask + twiddles are staged in LDS once per workgroup (the only workgroup barrier).  The
   // staging runs AFTER the first frame's global loads have been issued, so its latency and the
@@ -857,6 +963,14 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
       // the 4096 front end has no FFT: the mask's place holds the oscillator's (cos, sin) table,
       // whose per-sub-block lookup is otherwise a global load nothing hides at 4 waves per CU
       if (threadIdx.x < 128) dst[threadIdx.x] = reinterpret_cast<const float4 *>(a.tab + kTabSinCos)[threadIdx.x];
+    } else if (KEEP) {
+      // tw1 [7][64] and tw2 compacted to [7][8] -- 4032 B; the mask is read from the (L2-resident)
+      // constant table per frame instead: its loads are issued ahead of the forward FFT, which
+      // hides them, whereas the twiddles are needed the moment the FFT starts
+      if (threadIdx.x < 224) dst[threadIdx.x] = src[kTabTw1 / 2 + threadIdx.x];
+      else if (threadIdx.x >= 256 && threadIdx.x < 256 + 56)
+        reinterpret_cast<float2 *>(smem)[G::kTw2 + threadIdx.x - 256] =
+            a.tab[kTabTw2 + 64 * ((threadIdx.x - 256) >> 3) + ((threadIdx.x - 256) & 7)];
     } else {
       for (int i = threadIdx.x; i < (512 + 448) / 2; i += 256) dst[i] = src[i];  // mask, tw1
       if (threadIdx.x < 56)  // tw2[q][l1] = table entry [q][lane = l1]
@@ -873,7 +987,7 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
   }
 
   const cf *ltab = reinterpret_cast<const cf *>(smem);
-  float *lds = smem + kLdsTabFloats + wv * kLdsFloatsPerWave;
+  float *lds = smem + G::kTab + wv * G::kSlice;
   float *st = a.state + (size_t)(T41RX_ABLATE == 9 ? (ch & 15) : ch) * state_stride;
   // coefficients are read-only for the kernel: constant address space -> scalar (SMEM) loads,
   // re-derived through an opaque asm per phase so the compiler keeps the tap loads next to
@@ -901,6 +1015,8 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
   // the 4096 front end (PART 1: 8 segments per frame, only 4 waves per CU to hide anything)
   // requests the NEXT segment's first two sub-blocks while it finishes the current one.
   float4 pI0[2], pI1[2], pQ0[2], pQ1[2];
+  float4 tailN = make_float4(0, 0, 0, 0);  // KEEP: the next frame's last 256 I samples, 4 per lane
+  float2 tailNq = make_float2(0, 0);       // (WQ15: as q15 words)
   // PART 2 (4096 back end, same situation): interpolator histories and the next segment's audio
   cf nfm_carry = splat(0.0f);  // PART 1, NFM: the previous segment's last complex sample
   float4 hist1c = make_float4(0, 0, 0, 0);
@@ -967,10 +1083,18 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
       // order): sub-block 0, the I tail for Q's DC-block start state, the delay lines, then
       // sub-block 1.  Input prefetch runs TWO sub-blocks ahead (two register sets, even / odd).
       // PART 1, second and later segments of a call: the inputs are already on their way and the
-      // delay lines are still in LDS where the history rolls left them
-      const bool carried = (PART == 1) && f > 0;
+      // delay lines are still in LDS where the history rolls left them.  KEEP (PART 0), second and
+      // later frames of a launch: the delay lines likewise.
+      // KEEP: the same for the inputs -- the next frame's first two sub-blocks and its I tail are
+      // requested while the current frame's last two sub-blocks are processed and arrive under its
+      // back end, so a wave does not sit out a memory round trip at every frame start.
+      const bool hist_carried = (PART == 1 || KEEP) && f > 0;
+      const bool carried = (PART == 1 || (KEEP && T41RX_PF >= 1)) && f > 0;   // sub-block 0 (and the tail)
+      const bool carried1 = (PART == 1 || (KEEP && T41RX_PF >= 2)) && f > 0;  // sub-block 1
       float4 tailI;
-      if (!WQ15) {
+      if (KEEP && carried) {
+        tailI = WQ15 ? make_float4(q15_lo(tailNq.x), q15_hi(tailNq.x), q15_lo(tailNq.y), q15_hi(tailNq.y)) : tailN;
+      } else if (!WQ15) {
         if (!carried) {
           pI0[0] = ldg_stream(gI + 8 * lane);
           pI1[0] = ldg_stream(gI + 8 * lane + 4);
@@ -987,9 +1111,16 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
         tailI = make_float4(q15_lo(t.x), q15_hi(t.x), q15_lo(t.y), q15_hi(t.y));
       }
       float4 h1 = make_float4(0, 0, 0, 0), h2 = make_float4(0, 0, 0, 0);
-      if (!carried) {
+      float4 ovl0 = make_float4(0, 0, 0, 0), ovl1 = ovl0, ovl2 = ovl0;  // KEEP, first frame: overlap block, x2 history
+      if (!hist_carried) {
         if (lane < 14) h1 = *reinterpret_cast<const float4 *>(st + kStDec1 + 4 * lane);
         if (lane < 24) h2 = *reinterpret_cast<const float4 *>(st + kStDec2 + 4 * lane);
+        if (KEEP) {  // the rest of the channel's record: overlap block, interpolator histories
+          ovl0 = *reinterpret_cast<const float4 *>(st + kStOverlap + 4 * lane);
+          ovl1 = *reinterpret_cast<const float4 *>(st + kStOverlap + 256 + 4 * lane);
+          if (lane < 6) ovl2 = *reinterpret_cast<const float4 *>(st + kStInt1 + 4 * lane);
+          if (lane < 8) hist2c = st[kStInt2 + lane];
+        }
       }
       // gains (Process.cpp:117-134, 165-166).  g_band and -IQAmp are folded into one factor on I
       // (exact whenever either is +-1, which is the firmware default; one rounding otherwise)
@@ -1010,25 +1141,42 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
         }
       }
       STAMP(16);  // prologue a: issue + scalar (SMEM) gains
-      if (f == 0) stage_tables();
+      if (f == 0) {
+        stage_tables();
+        if (KEEP && a.stagger > 0) {
+          // De-synchronise the 16 waves of the CU for the rest of the launch: wave w starts its
+          // first frame order(w) * stagger * 64 cycles late, order = 4 (w / 4) + (w % 4) (waves w,
+          // w + 4, ... share a SIMD).  Waves that move through the frame in step all load, then all
+          // compute, then all store; spread over the frame period, one wave's loads and stores run
+          // under the arithmetic of the others.
+          const int order = ((wv >> 2) << 2) | (wv & 3);
+          for (int i = 0; i < order * a.stagger; i += 16) __builtin_amdgcn_s_sleep(16);
+        }
+      }
       STAMP(17);  // prologue b: table staging + workgroup barrier (first vmcnt wait)
       if (!WQ15) {
-        if (!carried) {
+        if (!carried1) {
           pI0[1] = ldg_stream(gI + 512 + 8 * lane);
           pI1[1] = ldg_stream(gI + 512 + 8 * lane + 4);
           pQ0[1] = ldg_stream(gQ + 512 + 8 * lane);
           pQ1[1] = ldg_stream(gQ + 512 + 8 * lane + 4);
         }
-      } else if (!carried) {
+      } else if (!carried1) {
         pI0[1] = ldg_stream(gI + 256 + 4 * lane);
         pQ0[1] = ldg_stream(gQ + 256 + 4 * lane);
       }
 
-      // ---- delay lines -> LDS (every frame is self-contained: load state, run, store state)
+      // ---- delay lines -> LDS (first frame of a launch / every segment-0; afterwards they are
+      // where the history rolls left them)
       wave_sync();
-      if (!carried) {
+      if (!hist_carried) {
         if (lane < 14) *reinterpret_cast<float4 *>(lds + kX + 2 * xpad(2 * lane)) = h1;
         if (lane < 24) *reinterpret_cast<float4 *>(lds + kY1 + 4 * lane) = h2;
+        if (KEEP) {
+          *reinterpret_cast<float4 *>(lds + G::kOV + 4 * lane) = ovl0;
+          *reinterpret_cast<float4 *>(lds + G::kOV + 256 + 4 * lane) = ovl1;
+          if (lane < 6) *reinterpret_cast<float4 *>(lds + G::kH1 + 4 * lane) = ovl2;
+        }
       }
       STAMP(18);  // prologue c: delay lines -> LDS
       if (f == 0) {
@@ -1062,6 +1210,11 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
 
       STAMP(15);  // prologue d: NCO/DC state uniformisation + Q's DC-block start state
       cf y2[2][2];  // /8 outputs of this frame: m = 128*round + 2*lane + e
+      float2 osc_tab;  // (cos, sin) table entry of this lane's first sample of the coming sub-block
+      {
+        const uint64_t P = phase0 + (uint64_t)(8 * lane + 1) * dphi;
+        osc_tab = (PART == 1) ? reinterpret_cast<const float2 *>(smem)[(int)(P >> 56)] : tab[kTabSinCos + (int)(P >> 56)];
+      }
 
   #pragma unroll
       for (int rd = 0; rd < 2; ++rd) {
@@ -1099,9 +1252,18 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
               pI0[h] = ldg_stream(gI + o);
               pQ0[h] = ldg_stream(gQ + o);
             }
-          } else if (PART == 1) {  // the next segment's sub-blocks 0 and 1 (same channel: contiguous)
+          } else if (PART == 1 || (KEEP && T41RX_PF >= 1)) {  // the next segment's / frame's sub-blocks 0 and 1 (same channel: contiguous)
             if (f + 1 < a.nframes) {
-              if (!WQ15) {
+              if (KEEP && s == 3) {  // and the I tail that decides the next frame's Q start state
+                if (!WQ15) {
+                  tailN = *reinterpret_cast<const float4 *>(gI + L + (L - 256) + 4 * lane);
+                } else {  // (raw q15 words; converted when used, not here: that would wait for them)
+                  tailNq = *reinterpret_cast<const float2 *>(gI + L / 2 + (L - 256) / 2 + 2 * lane);
+                }
+              }
+              if (KEEP && T41RX_PF < 2 && s == 3) {
+                // sub-block 1 is requested at the top of the next frame
+              } else if (!WQ15) {
                 const int o = L + 512 * (s - 2) + 8 * lane;
                 pI0[h] = ldg_stream(gI + o);
                 pI1[h] = ldg_stream(gI + o + 4);
@@ -1113,7 +1275,7 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
                 pQ0[h] = ldg_stream(gQ + o);
               }
             }
-          } else if (s == 3) {  // last sub-block: prefetch the overlap-save "previous" block instead
+          } else if (s == 3 && !KEEP) {  // last sub-block: prefetch the overlap-save "previous" block instead
             const cf *ov = reinterpret_cast<const cf *>(st + kStOverlap);
   #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = ov[64 * j + lane];
@@ -1160,16 +1322,21 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
   #pragma unroll
             for (int k = 0; k < 8; ++k) z[k] *= splat(amp[k]);
           }
+          // base phasor of my 8 samples from the 64-bit phase: 8-bit table entry (requested one
+          // sub-block ahead, so its L2 round trip is hidden) x 32-bit Taylor remainder
           cf base;
           {
             const uint64_t P = phase0 + (uint64_t)(n0 + 1) * dphi;
-            const float2 t = (PART == 1) ? reinterpret_cast<const float2 *>(smem)[(int)(P >> 56)] : tab[kTabSinCos + (int)(P >> 56)];
             const uint32_t u = (uint32_t)(P >> 24);
             const float ang = (float)u * (float)(6.283185307179586476925 / 256.0 / 4294967296.0);
             const float a2 = ang * ang;
             const float sn = ang * fmaf(a2, -1.0f / 6.0f, 1.0f);
             const float cs = fmaf(a2, fmaf(a2, 1.0f / 24.0f, -0.5f), 1.0f);
-            base = cmul(cf{t.x, t.y}, cf{cs, sn});
+            base = cmul(cf{osc_tab.x, osc_tab.y}, cf{cs, sn});
+            if (s < 3) {
+              const uint64_t Pn = P + (uint64_t)512 * dphi;
+              osc_tab = (PART == 1) ? reinterpret_cast<const float2 *>(smem)[(int)(Pn >> 56)] : tab[kTabSinCos + (int)(Pn >> 56)];
+            }
           }
           // -- Fs/4 shift (x j^n, Freq_Shift.cpp:42-65) and NCO mix (Freq_Shift.cpp:138-139):
           //    (I' + jQ') = (I + jQ) j^k conj(Osc_k) = (I + jQ) conj(base wk''),  wk'' = wk (-j)^k
@@ -1248,14 +1415,19 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
       if (PART == 0 || (f & (seg - 1)) == seg - 1) dc_carry = uniform_f32(dc2.y);  // the shared biquad ends the frame on Q
 
       STAMP(4);
-      // ---- delay lines back to HBM (the LDS copies are about to be reused as scratch); issue
-      // the small back-end history loads now so the FFT hides their latency
+      // ---- !KEEP: delay lines back to HBM (the LDS copies are about to be reused as scratch).
+      // Issue the small back-end loads now so the FFT hides their latency: interpolator histories,
+      // the AGC record; KEEP: the filter mask of this lane (8 x 8 B from the L2-resident table).
       wave_sync();
-      if (lane < 14) *reinterpret_cast<float4 *>(st + kStDec1 + 4 * lane) = lds4(lds + kX + 2 * xpad(2 * lane));
-      if (lane < 24) *reinterpret_cast<float4 *>(st + kStDec2 + 4 * lane) = lds4(lds + kY1 + 4 * lane);
-      if (PART != 1) {
-        if (lane < 6) hist1 = *reinterpret_cast<const float4 *>(st + kStInt1 + 4 * lane);
-        if (lane < 8) hist2 = st[kStInt2 + lane];
+      if (!KEEP) {
+        if (lane < 14) *reinterpret_cast<float4 *>(st + kStDec1 + 4 * lane) = lds4(lds + kX + 2 * xpad(2 * lane));
+        if (lane < 24) *reinterpret_cast<float4 *>(st + kStDec2 + 4 * lane) = lds4(lds + kY1 + 4 * lane);
+        if (PART != 1) {
+          if (lane < 6) hist1 = *reinterpret_cast<const float4 *>(st + kStInt1 + 4 * lane);
+          if (lane < 8) hist2 = st[kStInt2 + lane];
+        }
+      } else {
+        hist2 = hist2c;
       }
       if (AGC && lane < 52) agst = *reinterpret_cast<const float4 *>(st + st_agc(512) + 4 * lane);
       wave_sync();
@@ -1344,32 +1516,53 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
 
       // ---- overlap-save assemble (Process.cpp:498-522): v[0..3] = previous block, v[4..7] = new
       {
-        cf *tb = reinterpret_cast<cf *>(lds);
+        cf *tb = reinterpret_cast<cf *>(lds + kScr);
   #pragma unroll
         for (int rd = 0; rd < 2; ++rd)
-          *reinterpret_cast<float4 *>(lds + 2 * (128 * rd + 2 * lane)) =
+          *reinterpret_cast<float4 *>(lds + kScr + 2 * (128 * rd + 2 * lane)) =
               make_float4(y2[rd][0].x, y2[rd][0].y, y2[rd][1].x, y2[rd][1].y);
         wave_sync();
   #pragma unroll
         for (int j = 0; j < 4; ++j) v[4 + j] = tb[lane + 64 * j];
-        cf *ov = reinterpret_cast<cf *>(st + kStOverlap);
+        if (KEEP) {  // the previous block waits in LDS; the new one takes its place
+          cf *ov = reinterpret_cast<cf *>(lds + G::kOV);
   #pragma unroll
-        for (int j = 0; j < 4; ++j) ov[64 * j + lane] = v[4 + j];
+          for (int j = 0; j < 4; ++j) v[j] = ov[64 * j + lane];
+  #pragma unroll
+          for (int j = 0; j < 4; ++j) ov[64 * j + lane] = v[4 + j];
+        } else {
+          cf *ov = reinterpret_cast<cf *>(st + kStOverlap);
+  #pragma unroll
+          for (int j = 0; j < 4; ++j) ov[64 * j + lane] = v[4 + j];
+        }
       }
 
       STAMP(6);  // state save, level, overlap-save assemble
       // ---- FFT, x mask, inverse FFT (Process.cpp:535-595).  The mask table is pre-scaled by 1/N.
       {
         cf tw1[7], tw2[7];
+        cf mk[8];  // KEEP: FIR_filter_mask[lane + 64 r] / N, requested from the L2-resident table inside the forward FFT
+        if (!KEEP) {
   #pragma unroll
-        for (int q = 0; q < 7; ++q) {
-          tw1[q] = ltab[kLdsTabTw1 + 64 * q + lane];
-          tw2[q] = ltab[kLdsTabTw2 + 8 * q + (lane & 7)];
+          for (int q = 0; q < 7; ++q) {
+            tw1[q] = ltab[G::kTw1 + 64 * q + lane];
+            tw2[q] = ltab[G::kTw2 + 8 * q + (lane & 7)];
+          }
         }
         if (!T41RX_CUT(2)) {
-          fft512<false>(v, tw1, tw2, lds, lane);
+          if (KEEP) {
+            fft512_ldstw<false>(v, ltab + G::kTw1 + lane, ltab + G::kTw2 + (lane & 7), lds + kScr, lane, [&]() {
   #pragma unroll
-          for (int r = 0; r < 8; ++r) v[r] = cmul(v[r], ltab[kLdsTabMask + 64 * r + lane]);
+              for (int r = 0; r < 8; ++r) {
+                const float2 t = tab[kTabMask + 64 * r + lane];
+                mk[r] = cf{t.x, t.y};
+              }
+            });
+          } else {
+            fft512<false>(v, tw1, tw2, lds + kScr, lane);
+          }
+  #pragma unroll
+          for (int r = 0; r < 8; ++r) v[r] = cmul(v[r], KEEP ? mk[r] : ltab[kLdsTabMask + 64 * r + lane]);
           if (DEBUG && a.spect) {
             // ---- audio spectrum side output (Process.cpp:550-570 with updateDisplayFlag == 1):
             // audioSpectBuffer[1023 - k] = iFFT_buffer[k]^2 over the 1024 floats of the masked
@@ -1403,7 +1596,10 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
               st[kStMisc + kMiscMaxSqAve] = ave;
             }
           }
-          fft512<true>(v, tw1, tw2, lds, lane);
+          if (KEEP)
+            fft512_ldstw<true>(v, ltab + G::kTw1 + lane, ltab + G::kTw2 + (lane & 7), lds + kScr, lane, []() {});
+          else
+            fft512<true>(v, tw1, tw2, lds + kScr, lane);
         }
       }
     }
@@ -1413,8 +1609,9 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
       const float fixed_gain = fresh_coef(cf0)->sc[kScFixedGain];
       cf og[4];
       if (AGC) {
-        const int left = a.nchan - 4 * (int)blockIdx.x;
-        agc_apply(v, agst, lds, smem, st + st_agc(512 * seg), cf0, lane, wv, left < 4 ? left : 4, og STAMP_ARGS);
+        const int left = a.nchan - NW * (int)blockIdx.x;
+        agc_apply<AgcLds<KEEP>, NW, G::kSlice>(v, agst, lds, smem + G::kTab, st + st_agc(512 * seg), cf0, lane, wv,
+                                               left < NW ? left : NW, og STAMP_ARGS);
       }
       if (MODE != kModeAm) {
   #pragma unroll
@@ -1422,7 +1619,10 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
       } else {
         // ---- AM (Process.cpp:697-707): AlphaBetaMag envelope (Utility.cpp:269-285), DC removal
         // w = m + 0.99 w_old, y = w - w_old, then biquad_lowpass1 (DF1).  Both recurrences run as
-        // wave scans over lane-contiguous chunks of 4 samples.
+        // wave scans over lane-contiguous chunks of 4 samples.  No FMA contraction in this block:
+        // the reference's arithmetic is separate multiplies and adds, and every instantiation of
+        // the kernel (f32 / q15 entry, debug taps) must round alike.
+#pragma clang fp contract(off)
   #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const cf g = AGC ? og[j] : v[4 + j] * splat(fixed_gain);
@@ -1434,9 +1634,9 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
         if (!AGC) {  // lane + 64 j -> 4 lane + j
           wave_sync();
   #pragma unroll
-          for (int j = 0; j < 4; ++j) lds[24 + lane + 64 * j] = aud[j];
+          for (int j = 0; j < 4; ++j) lds[kI1 + 24 + lane + 64 * j] = aud[j];
           wave_sync();
-          m4 = lds4(lds + 24 + 4 * lane);
+          m4 = lds4(lds + kI1 + 24 + 4 * lane);
         }
         const float m[4] = {m4.x, m4.y, m4.z, m4.w};
         float *ms = st + kStMisc;
@@ -1560,12 +1760,14 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
     // LDS buf: [0] pad, [1..23] history, [24 + i] new sample i
     wave_sync();
     {
-      if (lane < 6) *reinterpret_cast<float4 *>(lds + 4 * lane) = hist1;
+      float *ib = lds + kI1;
+      if (KEEP && lane < 6) hist1 = lds4(lds + G::kH1 + 4 * lane);
+      if (lane < 6) *reinterpret_cast<float4 *>(ib + 4 * lane) = hist1;
       if (CONTIG) {
-        *reinterpret_cast<float4 *>(lds + 24 + 4 * lane) = make_float4(aud[0], aud[1], aud[2], aud[3]);
+        *reinterpret_cast<float4 *>(ib + 24 + 4 * lane) = make_float4(aud[0], aud[1], aud[2], aud[3]);
       } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) lds[24 + lane + 64 * j] = aud[j];
+        for (int j = 0; j < 4; ++j) ib[24 + lane + 64 * j] = aud[j];
       }
     }
     wave_sync();
@@ -1576,14 +1778,16 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
       float w[28];
 #pragma unroll
       for (int i = 0; i < 7; ++i) {
-        const float4 t = lds4(lds + 4 * lane + 4 * i);
+        const float4 t = lds4(lds + kI1 + 4 * lane + 4 * i);
         w[4 * i] = t.x;
         w[4 * i + 1] = t.y;
         w[4 * i + 2] = t.z;
         w[4 * i + 3] = t.w;
       }
-      if (lane < 6) {
-        hist1c = lds4(lds + 256 + 4 * lane);
+      if (KEEP) {  // next frame's history: to its LDS slot
+        if (lane < 6) *reinterpret_cast<float4 *>(lds + G::kH1 + 4 * lane) = lds4(lds + kI1 + 256 + 4 * lane);
+      } else if (lane < 6) {
+        hist1c = lds4(lds + kI1 + 256 + 4 * lane);
         *reinterpret_cast<float4 *>(st + kStInt1 + 4 * lane) = hist1c;
       }
       // arm_fir_interpolate_f32: out[2n + j - 1] = sum_t state[n + t] * c[(2 - j) + 2 t]:
@@ -1618,11 +1822,11 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) w[7 + i] = x1[i];
-      if (lane == 63) {
+      if (!KEEP && lane == 63) {
         *reinterpret_cast<float4 *>(st + kStInt2) = make_float4(0.0f, x1[1], x1[2], x1[3]);
         *reinterpret_cast<float4 *>(st + kStInt2 + 4) = make_float4(x1[4], x1[5], x1[6], x1[7]);
       }
-      if (PART == 2) {  // the same seven values, kept for the next segment: lane i = entry i
+      if (PART == 2 || KEEP) {  // the same seven values, kept for the next segment / frame: lane i = entry i
 #pragma unroll
         for (int i = 1; i < 8; ++i) {
           const float t = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x1[i]), 63));
@@ -1637,6 +1841,7 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
       // conflict-free both for these row writes and for the column reads below) ...
       wave_sync();
       unsigned qw[2] = {0u, 0u};  // WQ15: the four packed samples of the even u
+      float *tr = lds + kScr;
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         f2 o01 = splat(0.0f), o23 = splat(0.0f);
@@ -1649,15 +1854,30 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
         // ---- volume (Process.cpp:929)
         o01 *= splat(out_scale);
         o23 *= splat(out_scale);
-        if (!WQ15) {
-          *reinterpret_cast<float4 *>(lds + 4 * (8 * lane + (u ^ (lane & 7)))) = make_float4(o01.x, o01.y, o23.x, o23.y);
+        if (!WQ15 && !KEEP) {
+          *reinterpret_cast<float4 *>(tr + 4 * (8 * lane + (u ^ (lane & 7)))) = make_float4(o01.x, o01.y, o23.x, o23.y);
+        } else if (!WQ15) {
+          // KEEP: the transposition buffer is 1024 floats (the rest of the slice holds the channel's
+          // state), so the 32 outputs of a lane go out in two halves of 16 = 64 contiguous bytes per
+          // lane: slot 4 lane + ((u & 3) ^ swizzle), and a store instruction then writes 16 rows of 64 B
+          *reinterpret_cast<float4 *>(tr + 4 * (4 * lane + ((u & 3) ^ ((lane >> 2) & 3)))) = make_float4(o01.x, o01.y, o23.x, o23.y);
+          if ((u & 3) == 3) {
+            wave_sync();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {  // float4 F = 64 i + lane of this half: row F >> 2, column F & 3
+              const int row = 16 * i + (lane >> 2);
+              const float4 t = lds4(tr + 4 * (4 * row + ((lane & 3) ^ ((row >> 2) & 3))));
+              stg_stream(gO + 32 * row + 16 * (u >> 2) + 4 * (lane & 3), t);
+            }
+            wave_sync();
+          }
         } else if ((u & 1) == 0) {  // arm_float_to_q15 (Process.cpp:936)
           qw[0] = q15_pack2(o01.x, o01.y);
           qw[1] = q15_pack2(o23.x, o23.y);
         } else {
           // 8 samples = one 16-byte piece; a lane has 4 of them: slot 4 lane + (piece ^ swizzle)
           const int piece = u >> 1;
-          *reinterpret_cast<uint4 *>(lds + 4 * (4 * lane + (piece ^ ((lane >> 2) & 3)))) =
+          *reinterpret_cast<uint4 *>(tr + 4 * (4 * lane + (piece ^ ((lane >> 2) & 3)))) =
               make_uint4(qw[0], qw[1], q15_pack2(o01.x, o01.y), q15_pack2(o23.x, o23.y));
         }
       }
@@ -1665,18 +1885,18 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
       STAMP(12);  // x4 interpolator + LDS transpose writes
       // ... and every global store instruction then writes 1 KiB of consecutive addresses:
       // float4 index F = 64 i + lane lives in row F >> 3 = 8 i + (lane >> 3), column lane & 7
-      if (!WQ15) {
+      if (!WQ15 && !KEEP) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const int row = 8 * i + (lane >> 3);
-          const float4 t = lds4(lds + 4 * (8 * row + ((lane & 7) ^ (row & 7))));
+          const float4 t = lds4(tr + 4 * (8 * row + ((lane & 7) ^ (row & 7))));
           stg_stream(gO + 256 * i + 4 * lane, t);
         }
-      } else {  // 4 pieces per row: piece F = 64 i + lane is row F >> 2, column lane & 3
+      } else if (WQ15) {  // 4 pieces per row: piece F = 64 i + lane is row F >> 2, column lane & 3
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int row = 16 * i + (lane >> 2);
-          const float4 t = lds4(lds + 4 * (4 * row + ((lane & 3) ^ ((row >> 2) & 3))));
+          const float4 t = lds4(tr + 4 * (4 * row + ((lane & 3) ^ ((row >> 2) & 3))));
           stg_stream(gO + 256 * i + 4 * lane, t);
         }
       }
@@ -1694,6 +1914,15 @@ __global__ __launch_bounds__(256, 4) void rx512_kernel(const RxArgs a) {
     reinterpret_cast<unsigned long long *>(a.dbg_demod + (size_t)a.nchan * a.nframes * D)[(size_t)ch * 64 + lane] = stamp_acc;
 #endif
 
+  if (KEEP) {  // the channel's record goes back to HBM once per launch
+    wave_sync();
+    if (lane < 14) *reinterpret_cast<float4 *>(st + kStDec1 + 4 * lane) = lds4(lds + kX + 2 * xpad(2 * lane));
+    if (lane < 24) *reinterpret_cast<float4 *>(st + kStDec2 + 4 * lane) = lds4(lds + kY1 + 4 * lane);
+    *reinterpret_cast<float4 *>(st + kStOverlap + 4 * lane) = lds4(lds + G::kOV + 4 * lane);
+    *reinterpret_cast<float4 *>(st + kStOverlap + 256 + 4 * lane) = lds4(lds + G::kOV + 256 + 4 * lane);
+    if (lane < 6) *reinterpret_cast<float4 *>(st + kStInt1 + 4 * lane) = lds4(lds + G::kH1 + 4 * lane);
+    if (lane < 8) st[kStInt2 + lane] = (lane == 0) ? 0.0f : hist2c;
+  }
   if (PART != 2 && lane == 0) {
     ncs->phase = phase0;
     ncs->r = osc_r;
@@ -1841,34 +2070,36 @@ __global__ __launch_bounds__(256) void fastconv_kernel(const RxArgs a) {
 // ------------------------------------------------------------------------------------------
 template <int MODE>
 static hipError_t launch512(const RxArgs &a, hipStream_t s, bool debug) {
-  const int grid = (a.nchan + 3) / 4;
-  // 40 KiB of dynamic LDS per workgroup pins residency at exactly 4 workgroups (16 waves)
-  // per CU, so a 4096-channel batch is one full, balanced wave of work on 256 CUs.
-  const size_t lds = 40960;
-  static_assert((kLdsTabFloats + 4 * kLdsFloatsPerWave) * sizeof(float) <= 40960, "LDS slice too large");
+  // One 16-wave workgroup per CU (all 160 KiB of LDS, declared statically by the kernel): a
+  // 4096-channel batch is one full, balanced wave of work on 256 CUs, and every wave keeps its
+  // channel for all the frames of the launch.
+  constexpr int NW = Geo<0>::kWaves;
+  const dim3 grid((a.nchan + NW - 1) / NW), block(NW * 64);
+#define T41RX_GO(DBG, PLN, AGCv, Q15v) hipLaunchKernelGGL((rx512_kernel<MODE, DBG, 0, PLN, AGCv, Q15v>), grid, block, 0, s, a)
   if (a.q15) {  // the firmware's q15 sample format either side (no debug taps: refused by the host)
     if (a.agc) {
       if (a.plain)
-        hipLaunchKernelGGL((rx512_kernel<MODE, false, 0, true, true, true>), dim3(grid), dim3(256), lds, s, a);
+        T41RX_GO(false, true, true, true);
       else
-        hipLaunchKernelGGL((rx512_kernel<MODE, false, 0, false, true, true>), dim3(grid), dim3(256), lds, s, a);
+        T41RX_GO(false, false, true, true);
     } else if (a.plain)
-      hipLaunchKernelGGL((rx512_kernel<MODE, false, 0, true, false, true>), dim3(grid), dim3(256), lds, s, a);
+      T41RX_GO(false, true, false, true);
     else
-      hipLaunchKernelGGL((rx512_kernel<MODE, false, 0, false, false, true>), dim3(grid), dim3(256), lds, s, a);
+      T41RX_GO(false, false, false, true);
   } else if (a.agc) {
     if (debug)
-      hipLaunchKernelGGL((rx512_kernel<MODE, true, 0, false, true>), dim3(grid), dim3(256), lds, s, a);
+      T41RX_GO(true, false, true, false);
     else if (a.plain)
-      hipLaunchKernelGGL((rx512_kernel<MODE, false, 0, true, true>), dim3(grid), dim3(256), lds, s, a);
+      T41RX_GO(false, true, true, false);
     else
-      hipLaunchKernelGGL((rx512_kernel<MODE, false, 0, false, true>), dim3(grid), dim3(256), lds, s, a);
+      T41RX_GO(false, false, true, false);
   } else if (debug)
-    hipLaunchKernelGGL((rx512_kernel<MODE, true, 0, false>), dim3(grid), dim3(256), lds, s, a);
+    T41RX_GO(true, false, false, false);
   else if (a.plain)
-    hipLaunchKernelGGL((rx512_kernel<MODE, false, 0, true>), dim3(grid), dim3(256), lds, s, a);
+    T41RX_GO(false, true, false, false);
   else
-    hipLaunchKernelGGL((rx512_kernel<MODE, false, 0, false>), dim3(grid), dim3(256), lds, s, a);
+    T41RX_GO(false, false, false, false);
+#undef T41RX_GO
   return hipGetLastError();
 }
 
@@ -1877,13 +2108,13 @@ static hipError_t launch_long(const RxArgs &a, int mode, hipStream_t s) {
   const int grid = (a.nchan + 3) / 4;
   if (mode == T41RX_DEMOD_NFM) {
     if (a.q15)
-      hipLaunchKernelGGL((rx512_kernel<kModeNfm, false, 1, false, false, true>), dim3(grid), dim3(256), 40960, s, a);
+      hipLaunchKernelGGL((rx512_kernel<kModeNfm, false, 1, false, false, true>), dim3(grid), dim3(256), 0, s, a);
     else
-      hipLaunchKernelGGL((rx512_kernel<kModeNfm, false, 1, false>), dim3(grid), dim3(256), 40960, s, a);
+      hipLaunchKernelGGL((rx512_kernel<kModeNfm, false, 1, false>), dim3(grid), dim3(256), 0, s, a);
   } else if (a.q15) {
-    hipLaunchKernelGGL((rx512_kernel<kModeSsb, false, 1, false, false, true>), dim3(grid), dim3(256), 40960, s, a);
+    hipLaunchKernelGGL((rx512_kernel<kModeSsb, false, 1, false, false, true>), dim3(grid), dim3(256), 0, s, a);
   } else {
-    hipLaunchKernelGGL((rx512_kernel<kModeSsb, false, 1, false>), dim3(grid), dim3(256), 40960, s, a);
+    hipLaunchKernelGGL((rx512_kernel<kModeSsb, false, 1, false>), dim3(grid), dim3(256), 0, s, a);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
@@ -1907,9 +2138,9 @@ static hipError_t launch_long(const RxArgs &a, int mode, hipStream_t s) {
 #define T41RX_BACK(MODEv, AGCv)                                                                                   \
   do {                                                                                                            \
     if (a.q15)                                                                                                    \
-      hipLaunchKernelGGL((rx512_kernel<MODEv, false, 2, false, AGCv, true>), dim3(grid), dim3(256), 40960, s, a); \
+      hipLaunchKernelGGL((rx512_kernel<MODEv, false, 2, false, AGCv, true>), dim3(grid), dim3(256), 0, s, a); \
     else                                                                                                          \
-      hipLaunchKernelGGL((rx512_kernel<MODEv, false, 2, false, AGCv, false>), dim3(grid), dim3(256), 40960, s, a); \
+      hipLaunchKernelGGL((rx512_kernel<MODEv, false, 2, false, AGCv, false>), dim3(grid), dim3(256), 0, s, a); \
   } while (0)
   if (mode == T41RX_DEMOD_AM) {
     if (a.agc)

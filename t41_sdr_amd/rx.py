@@ -80,6 +80,12 @@ class RxChain:
         a = np.ascontiguousarray(np.broadcast_to(np.asarray(NCOFreq, dtype=np.int32), (self.n_channels,)))
         check(self._lib.t41rx_set_nco_freq(self._ctx, a.ctypes.data_as(C.POINTER(C.c_int32)), self.n_channels))
 
+    def get_params(self):
+        """the parameters the context runs with (after set_coeffs(): the ones the blob was designed for)"""
+        p = Params()
+        check(self._lib.t41rx_get_params(self._ctx, C.byref(p)))
+        return p
+
     def coeffs(self):
         n = self._lib.t41rx_coeff_blob_bytes(self.params.fft_length)
         blob = np.zeros(n, dtype=np.uint8)

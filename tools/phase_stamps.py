@@ -25,7 +25,8 @@ def main():
     nch = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     agc = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     fft = int(sys.argv[3]) if len(sys.argv) > 3 else 512  # 4096: stamps of the front kernel (8 segments)
-    L, D = 4 * fft, (256 if fft == 512 else 8 * 256)
+    nfr = int(sys.argv[4]) if len(sys.argv) > 4 else 1    # frames per launch (cycles are then summed over them)
+    L, D = 4 * fft * nfr, (256 if fft == 512 else 8 * 256) * nfr
     kw = dict(AGCMode=agc) if fft == 512 else dict(fft_length=4096, FLoCut=400, FHiCut=600)
     rx = T.RxChain(nch, T.default_params(**kw), NCOFreq=np.full(nch, 5000, np.int32))
     g = torch.Generator(device="cuda").manual_seed(0)
@@ -44,7 +45,9 @@ def main():
     torch.cuda.synchronize()
     st = buf[nch * D:].view(torch.int64).view(nch, 64).cpu().numpy().astype(np.float64)
     tot = st[:, :len(NAMES)].sum(axis=1)
-    print("channels %d: mean wave cycles %.0f (min %.0f max %.0f)" % (nch, tot.mean(), tot.min(), tot.max()))
+    st[:, :len(NAMES)] /= nfr
+    tot /= nfr
+    print("channels %d x %d frames per launch: mean wave cycles per frame %.0f (min %.0f max %.0f)" % (nch, nfr, tot.mean(), tot.min(), tot.max()))
     for p, name in enumerate(NAMES):
         print("  %2d %-30s %8.0f cycles  %5.1f %%" % (p, name, st[:, p].mean(), 100 * st[:, p].mean() / tot.mean()))
 

@@ -57,8 +57,8 @@ __device__ __forceinline__ void wave_sync() {
 }
 
 // Timing experiments (tools/build_ablations.sh): T41RX_ABLATE = n cuts stages from the END of the
-// chain (1 interpolators, 2 FFTs, 3 /2 decimator, 4 /4 decimator, 5 NCO, 6 DC high-pass, 7/8 ideal
-// store/load patterns); 9 keeps all arithmetic but makes every wave use the same 16 channels'
+// chain (1 interpolators, 2 FFTs, 3 /2 decimator, 4 /4 decimator, 5 NCO, 6 DC high-pass, 7 1-KiB
+// store instructions, 8 the fused kernel's 16 x 64 B store instructions); 9 keeps all arithmetic but makes every wave use the same 16 channels'
 // buffers (cache-resident I/O).  Outputs are WRONG for n > 0; the product builds with 0.
 #ifndef T41RX_ABLATE
 #define T41RX_ABLATE 0
@@ -70,12 +70,40 @@ __device__ __forceinline__ void wave_sync() {
 #ifndef T41RX_PF
 #define T41RX_PF 2
 #endif
+#ifndef T41RX_OSC_TOP
+#define T41RX_OSC_TOP 1  // 0 (experiments): oscillator table lookup at the point of use, inside the sub-block
+#endif
 // Issue priority falls as a wave advances through its frame (3: loads, mixer, decimators; 2:
 // FFTs and demodulator; 0: interpolators and stores), so the waves sharing a SIMD progress evenly
 // instead of oldest-first, which left each SIMD with one or two latency-bound waves for the last
 // third of the launch (per-wave end times from the -DT41RX_STAMP build: 24 .. 35 us within every
 // CU).  Measured: 33.8 -> 31.6 us; eight other schedules tried, rising priorities lose 0.2 us.
+// T41RX_PRIO_MODE (experiments): 0 = the schedule above; 1 = no priorities; 2 = one priority per
+// (wave, frame), rotating, so that the waves sharing a SIMD take turns at every level
+#ifndef T41RX_PRIO_MODE
+#define T41RX_PRIO_MODE 0
+#endif
+#if T41RX_PRIO_MODE == 0
 #define PRIO(n) __builtin_amdgcn_s_setprio(n)
+#else
+#define PRIO(n) do {} while (0)
+#endif
+#ifndef T41RX_FRESH
+#define T41RX_FRESH 1
+#endif
+// bisection experiments on the non-resident geometry: the resident kernel's output transposition
+// (two halves, 64-byte store segments) / its FFT (twiddles at use, mask from the global table)
+#ifndef T41RX_X_HALFTR
+#define T41RX_X_HALFTR 0
+#endif
+#ifndef T41RX_X_GMASK
+#define T41RX_X_GMASK 0
+#endif
+#if T41RX_FRESH
+#define FRESH_LANE() asm volatile("" : "+v"(lane))
+#else
+#define FRESH_LANE() do {} while (0)
+#endif
 
 // Diagnostic build only (-DT41RX_STAMP): s_memtime stamps at phase boundaries; lane p of each wave
 // accumulates the cycles of phase p and writes them behind the demod debug tap at the end.
@@ -168,6 +196,10 @@ __device__ __forceinline__ void dft8(cf (&v)[8]) {
 // LDS exchange buffer row stride for the FFT transposes (in complex elements): 64 + 8 keeps
 // both the row-major writes and the 8-strided reads bank-conflict-free for ds_*_b64.
 constexpr int kFftRow = 72;
+// Second exchange: element (q, l1) of a row sits at q + 8 l1 + (l1 & 6).  The extra term spreads
+// the ds_write_b64 of 16 consecutive lanes (q in {2g, 2g+1}, l1 = 0..7) over all 16 8-byte bank
+// pairs (plain 8 l1 is 4-way conflicted: 8 l1 mod 16 has two values); rows stay disjoint (max 69).
+__device__ __forceinline__ constexpr int fft_x2(int l1) { return 8 * l1 + (l1 & 6); }
 
 // 512-point complex FFT held as 8 points per lane: lane l register r <-> element l + 64 r,
 // on input AND output (natural order both ways, no bit-reversal pass).
@@ -200,13 +232,13 @@ __device__ __forceinline__ void fft512(cf (&v)[8], const cf (&tw1)[7], const cf 
   {
     const int l1 = lane & 7, q = lane >> 3;
 #pragma unroll
-    for (int q2 = 0; q2 < 8; ++q2) xb[q2 * kFftRow + q + 8 * l1] = v[q2];
+    for (int q2 = 0; q2 < 8; ++q2) xb[q2 * kFftRow + q + fft_x2(l1)] = v[q2];
   }
   wave_sync();
   {
     const int q = lane & 7, q2 = lane >> 3;
 #pragma unroll
-    for (int l1 = 0; l1 < 8; ++l1) v[l1] = xb[q2 * kFftRow + q + 8 * l1];
+    for (int l1 = 0; l1 < 8; ++l1) v[l1] = xb[q2 * kFftRow + q + fft_x2(l1)];
   }
   dft8<INV>(v);
 }
@@ -246,13 +278,13 @@ __device__ __forceinline__ void fft512_ldstw(cf (&v)[8], const cf *tw1l, const c
   {
     const int l1 = lane & 7, q = lane >> 3;
 #pragma unroll
-    for (int q2 = 0; q2 < 8; ++q2) xb[q2 * kFftRow + q + 8 * l1] = v[q2];
+    for (int q2 = 0; q2 < 8; ++q2) xb[q2 * kFftRow + q + fft_x2(l1)] = v[q2];
   }
   wave_sync();
   {
     const int q = lane & 7, q2 = lane >> 3;
 #pragma unroll
-    for (int l1 = 0; l1 < 8; ++l1) v[l1] = xb[q2 * kFftRow + q + 8 * l1];
+    for (int l1 = 0; l1 < 8; ++l1) v[l1] = xb[q2 * kFftRow + q + fft_x2(l1)];
   }
   dft8<INV>(v);
 }
@@ -373,9 +405,8 @@ __device__ __forceinline__ float uniform_f32(float v) {
 //      (5 is odd: any 16 lanes distinct mod 16 hit 16 distinct slots) and (b) every lane sees
 //      the pads at the same offsets of its window, i.e. all LDS offsets are immediates.
 //      Doubles as FFT exchange / transposition scratch.
-// Y1 : /4 decimator outputs of two sub-blocks (256) + 48-entry history, unpadded
-//      (lane stride 2 slots: 2-way conflicts on 52 reads per frame, cheaper than the LDS a
-//      per-lane pad would cost).  logical j: [0..2] pad, [3..47] history, [48+m] new.
+// Y1 : /4 decimator outputs of two sub-blocks (256) + 48-entry history = 304 complex, logical j:
+//      [0..2] pad, [3..47] history, [48+m] new; stored as two planes of even / odd slots (y1slot()).
 constexpr int kLdsTabMask = 0, kLdsTabTw1 = 512, kLdsTabTw2 = 512 + 448;  // float2 units
 constexpr int kLdsTabFloats = 2 * (512 + 448 + 56);                          // 2032 floats
 constexpr int kXFloats = 1352;  // 2 * (xpad(539) + 1) = 1348, rounded to 16 B
@@ -387,6 +418,13 @@ constexpr int kLdsFloatsPerWave = 2052;
 static_assert(kXFloats + kY1Floats <= kLdsFloatsPerWave && kLdsFloatsPerWave >= 2048, "slice too small");
 static_assert(kXFloats >= 8 * kFftRow * 2, "FFT exchange buffer must fit in X");
 __device__ __forceinline__ constexpr int xpad(int j) { return j + ((j >> 3) << 1); }  // complex units
+// Y1 is stored as two planes of 76 16-byte slots: slot s (complex 2s, 2s+1) of the logical array
+// lives in plane s & 1 at position s >> 1.  The /2 decimator's window of lane l starts at slot 2 l,
+// so with a linear layout the 16 lanes a ds_read_b128 serves together sit 2 slots apart and collide
+// pairwise; split by parity, each read walks one plane with a lane stride of one slot.  Offsets stay
+// immediates: window slot i of lane l = plane (i & 1), position l + (i >> 1).
+constexpr int kY1Plane = 76;  // slots per plane (304 complex)
+__device__ __forceinline__ constexpr int y1slot(int s) { return 4 * ((s & 1) * kY1Plane + (s >> 1)); }  // float offset of slot s
 
 typedef const __attribute__((address_space(4))) DevCoef *CoefPtr;
 __device__ __forceinline__ CoefPtr fresh_coef(CoefPtr p) {
@@ -521,11 +559,15 @@ struct AgcLds {
   static constexpr int G = A + 356;                  // max of every aligned group of four |z| (89 used)
   static constexpr int S = RESIDENT ? G + 92 : 1928; // the 8 state words (rx_internal.hpp: kAgcSt*)
   static constexpr int R = RESIDENT ? A : 1160;      // ring_max[256]; the chain replaces it by volts[256]
-  static constexpr int P = RESIDENT ? 1348 + 96 : 1416;  // (fast_backmult, hang_backmult) * abs_out_sample, [256] pairs
-  static constexpr int kEnd = RESIDENT ? 1348 + 608 : 1936;
+  // (fast_backmult, hang_backmult) * abs_out_sample, [256] pairs, in two halves of 128 pairs: the
+  // resident layout puts them behind the 12 history slots of either Y1 plane
+  static constexpr int P0 = RESIDENT ? 1348 + 48 : 1416;
+  static constexpr int P1 = RESIDENT ? 1348 + 4 * kY1Plane + 48 : 1416 + 256;
+  __device__ static constexpr int pofs(int i) { return i < 256 ? P0 + i : P1 + i - 256; }  // float i of the 512
 };
 static_assert(AgcLds<false>::S + kAgcScalars <= kLdsFloatsPerWave, "AGC scratch must fit the wave slice");
-static_assert(AgcLds<true>::S + kAgcScalars <= 1348 && AgcLds<true>::P + 512 <= AgcLds<true>::kEnd, "AGC scratch vs resident state");
+static_assert(AgcLds<true>::S + kAgcScalars <= 1348 && AgcLds<true>::P0 + 256 <= 1348 + 4 * kY1Plane &&
+              AgcLds<true>::P1 + 256 <= 1348 + 608, "AGC scratch vs resident state");
 static_assert(kAgcDelay == 97 && kAgcHist == 100, "window arithmetic below is written for 97 / 100");
 #ifndef T41RX_AGC_COOP
 #define T41RX_AGC_COOP 1
@@ -734,7 +776,7 @@ __device__ __forceinline__ lanemask agc_fast_block(AgcState &st, AgcLane &d, con
 
 template <typename AL>
 __device__ __forceinline__ void agc_chain(float *sl, CoefPtr cf0, int lane STAMP_PARAMS) {
-  constexpr int kAgR = AL::R, kAgP = AL::P, kAgS = AL::S;
+  constexpr int kAgR = AL::R, kAgS = AL::S;
   const CoefPtr c = fresh_coef(cf0);
   AgcConsts g;
   g.attack_mult = c->agc[kAgcAttackMult];
@@ -751,13 +793,13 @@ __device__ __forceinline__ void agc_chain(float *sl, CoefPtr cf0, int lane STAMP
   const int4 si = *reinterpret_cast<const int4 *>(sl + kAgS + 4);
   AgcState st{sf.x, sf.y, sf.z, sf.w, si.x, si.y, si.z};
   AgcLane d = agc_lane_of(st, g);
-  float4 nr4 = lds4(sl + kAgR), npa = lds4(sl + kAgP), npb = lds4(sl + kAgP + 4);
+  float4 nr4 = lds4(sl + kAgR), npa = lds4(sl + AL::pofs(0)), npb = lds4(sl + AL::pofs(4));
   for (int b = 0; b < 64; ++b) {
     const float4 r4 = nr4, pa = npa, pb = npb;
     if (b < 63) {  // the next four steps' operands, ahead of the dependent chain
       nr4 = lds4(sl + kAgR + 4 * b + 4);
-      npa = lds4(sl + kAgP + 8 * b + 8);
-      npb = lds4(sl + kAgP + 8 * b + 12);
+      npa = lds4(sl + AL::pofs(8 * b + 8));
+      npb = lds4(sl + AL::pofs(8 * b + 12));
     }
     const float rm[4] = {r4.x, r4.y, r4.z, r4.w};
     const float pf[4] = {pa.x, pa.z, pb.x, pb.z}, ph[4] = {pa.y, pa.w, pb.y, pb.w};
@@ -798,7 +840,7 @@ __device__ __forceinline__ void agc_chain(float *sl, CoefPtr cf0, int lane STAMP
 template <typename AL, int NW, int SLICE>
 __device__ __forceinline__ void agc_apply(const cf (&v)[8], float4 agst, float *lds, float *slices, float *st_ag,
                                           CoefPtr cf0, int lane, int wv, int nvalid, cf (&og)[4] STAMP_PARAMS) {
-  constexpr int kAgZ = AL::Z, kAgA = AL::A, kAgG = AL::G, kAgR = AL::R, kAgP = AL::P, kAgS = AL::S;
+  constexpr int kAgZ = AL::Z, kAgA = AL::A, kAgG = AL::G, kAgR = AL::R, kAgS = AL::S;
   wave_sync();
   if (lane < 50) *reinterpret_cast<float4 *>(lds + kAgZ + 4 * lane) = agst;
   else if (lane < 52) *reinterpret_cast<float4 *>(lds + kAgS + 4 * (lane - 50)) = agst;
@@ -837,9 +879,9 @@ __device__ __forceinline__ void agc_apply(const cf (&v)[8], float4 agst, float *
     const float ao[4] = {ao0, g1.x, g1.y, g1.z};
     {
 #pragma clang fp contract(off)
-      *reinterpret_cast<float4 *>(lds + kAgP + 8 * lane) =
+      *reinterpret_cast<float4 *>(lds + AL::pofs(8 * lane)) =
           make_float4(fast_backmult * ao[0], hang_backmult * ao[0], fast_backmult * ao[1], hang_backmult * ao[1]);
-      *reinterpret_cast<float4 *>(lds + kAgP + 8 * lane + 4) =
+      *reinterpret_cast<float4 *>(lds + AL::pofs(8 * lane + 4)) =
           make_float4(fast_backmult * ao[2], hang_backmult * ao[2], fast_backmult * ao[3], hang_backmult * ao[3]);
     }
   }
@@ -907,18 +949,21 @@ constexpr int kModeSsb = 0, kModeAm = 1, kModeNfm = 2;  // kernel template MODE
 // PART 0 -- the fused FFT_LENGTH 512 chain -- runs as ONE 16-wave workgroup per CU that owns all
 // 160 KiB of LDS: [tw1, tw2 1024 | 16 wave slices of 2496].  A wave keeps its channel's streaming
 // state ON CHIP across the frames of a launch: the /4 and /2 delay lines stay where the history
-// rolls leave them (X[0..68), Y1[0..96)), the overlap-save block and the x2 interpolator history
+// rolls leave them (X[0..68), the first 12 slots of either Y1 plane), the overlap-save block and the x2 interpolator history
 // have their own slots (OV, H1), the x4 history and the NCO / DC scalars live in registers.  HBM
 // state is read before the first frame and written after the last.  Everything the back end needs
 // as scratch (FFT exchange, AGC, x2 window, output transposition in two halves) therefore avoids
-// those regions: it lives in X[80 ..) and the free part of Y1.  Only the FFT twiddles are staged in
+// those regions: it lives in X[80 ..) (and, for the AGC, the free parts of Y1).  Only the FFT twiddles are staged in
 // LDS; the filter mask comes from the (L2-resident) constant table per frame: that is what makes
 // the slices fit.
 // PART 1 / 2 -- the two ends of the long-FFT pipeline -- keep 4-wave workgroups, 4 per CU:
 // [mask, tw1, tw2 2032 | 4 slices of 2052], scratch from the start of the slice.
+#ifndef T41RX_RESIDENT
+#define T41RX_RESIDENT 1  // 0 (experiments): the fused kernel with the 4-wave geometry and per-frame HBM state
+#endif
 template <int PART>
 struct Geo {
-  static constexpr bool kResident = (PART == 0);
+  static constexpr bool kResident = (PART == 0) && T41RX_RESIDENT;
   static constexpr int kWaves = kResident ? 16 : 4;
   static constexpr int kTab = kResident ? 1024 : kLdsTabFloats;
   static constexpr int kTw1 = kResident ? 0 : kLdsTabTw1;        // float2 units within the tables
@@ -931,12 +976,12 @@ struct Geo {
   static constexpr int kOV = kY1 + kY1Floats;   // resident: overlap-save "previous" block, 256 complex in [j][lane] order
   static constexpr int kH1 = kOV + 512;         // resident: x2 interpolator history, 24 floats
   static constexpr int kScr = kResident ? 80 : 0;        // FFT exchange (1152), overlap assembly, output transposition
-  static constexpr int kI1 = kResident ? kY1 + 96 : 0;   // x2 interpolator window: 24 history + 256 new
+  static constexpr int kI1 = kScr;                       // x2 interpolator window: 24 history + 256 new
 };
-static_assert(Geo<0>::kTotal * sizeof(float) == 160 * 1024, "PART 0: one workgroup owns the CU's LDS");
+static_assert(!Geo<0>::kResident || Geo<0>::kTotal * sizeof(float) == 160 * 1024, "PART 0: one workgroup owns the CU's LDS");
 static_assert(Geo<1>::kTotal * sizeof(float) == 40960, "PART 1/2: four workgroups per CU");
-static_assert(Geo<0>::kH1 + 24 <= Geo<0>::kSlice && Geo<0>::kScr + 8 * kFftRow * 2 <= Geo<0>::kXF &&
-              Geo<0>::kI1 + 284 <= Geo<0>::kOV && Geo<0>::kScr >= 68, "resident LDS layout");
+static_assert(!Geo<0>::kResident || (Geo<0>::kH1 + 24 <= Geo<0>::kSlice && Geo<0>::kScr + 8 * kFftRow * 2 <= Geo<0>::kXF &&
+                                     Geo<0>::kI1 + 284 <= Geo<0>::kXF && Geo<0>::kScr >= 68), "resident LDS layout");
 
 template <int MODE, bool DEBUG, int PART, bool PLAIN, bool AGC = false, bool WQ15 = false>
 __global__ __launch_bounds__(Geo<PART>::kWaves * 64, 4) void rx512_kernel(const RxArgs a) {
@@ -949,7 +994,10 @@ __global__ __launch_bounds__(Geo<PART>::kWaves * 64, 4) void rx512_kernel(const 
   // per-channel state record size follows fft_length = 512 * (segments per frame)
   const int seg = (PART == 0) ? 1 : a.seg;
   const size_t state_stride = state_floats(512 * seg);
-  const int lane = threadIdx.x & 63;
+  // `lane` is re-defined through an opaque asm at every phase boundary (FRESH_LANE): addresses
+  // derived from it are then recomputed per phase (one or two VALU instructions each) instead of
+  // being hoisted out of the frame loop, kept live through every other phase and spilled.
+  int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ch = blockIdx.x * NW + wv;
 
@@ -1037,6 +1085,15 @@ __global__ __launch_bounds__(Geo<PART>::kWaves * 64, 4) void rx512_kernel(const 
 #endif
   for (int f = 0; f < a.nframes; ++f) {
     PRIO(3);
+    FRESH_LANE();
+#if T41RX_PRIO_MODE == 2
+    switch (((wv >> 2) + f) & 3) {
+      case 0: __builtin_amdgcn_s_setprio(0); break;
+      case 1: __builtin_amdgcn_s_setprio(1); break;
+      case 2: __builtin_amdgcn_s_setprio(2); break;
+      default: __builtin_amdgcn_s_setprio(3); break;
+    }
+#endif
     const size_t fbase = ((size_t)(T41RX_ABLATE == 9 ? (ch & 15) : ch) * a.nframes + f) * L;
     // (WQ15: two samples per float slot, so sample offsets halve)
     const float *__restrict__ gI = a.I + (WQ15 ? fbase / 2 : fbase);
@@ -1171,7 +1228,7 @@ __global__ __launch_bounds__(Geo<PART>::kWaves * 64, 4) void rx512_kernel(const 
       wave_sync();
       if (!hist_carried) {
         if (lane < 14) *reinterpret_cast<float4 *>(lds + kX + 2 * xpad(2 * lane)) = h1;
-        if (lane < 24) *reinterpret_cast<float4 *>(lds + kY1 + 4 * lane) = h2;
+        if (lane < 24) *reinterpret_cast<float4 *>(lds + kY1 + y1slot(lane)) = h2;
         if (KEEP) {
           *reinterpret_cast<float4 *>(lds + G::kOV + 4 * lane) = ovl0;
           *reinterpret_cast<float4 *>(lds + G::kOV + 256 + 4 * lane) = ovl1;
@@ -1210,11 +1267,18 @@ __global__ __launch_bounds__(Geo<PART>::kWaves * 64, 4) void rx512_kernel(const 
 
       STAMP(15);  // prologue d: NCO/DC state uniformisation + Q's DC-block start state
       cf y2[2][2];  // /8 outputs of this frame: m = 128*round + 2*lane + e
-      float2 osc_tab;  // (cos, sin) table entry of this lane's first sample of the coming sub-block
-      {
-        const uint64_t P = phase0 + (uint64_t)(8 * lane + 1) * dphi;
-        osc_tab = (PART == 1) ? reinterpret_cast<const float2 *>(smem)[(int)(P >> 56)] : tab[kTabSinCos + (int)(P >> 56)];
+      // (cos, sin) table entries of this lane's first sample of the four sub-blocks.  All four
+      // are requested HERE and nowhere later: vector-memory results return in issue order, so a
+      // table read issued between two input requests could only be used once every older input
+      // request has landed -- it would cut the two-sub-block prefetch distance to nothing.
+#if T41RX_OSC_TOP
+      float2 osc_tab[4];
+  #pragma unroll
+      for (int sb = 0; sb < 4; ++sb) {
+        const uint64_t P = phase0 + (uint64_t)(512 * sb + 8 * lane + 1) * dphi;
+        osc_tab[sb] = (PART == 1) ? reinterpret_cast<const float2 *>(smem)[(int)(P >> 56)] : tab[kTabSinCos + (int)(P >> 56)];
       }
+#endif
 
   #pragma unroll
       for (int rd = 0; rd < 2; ++rd) {
@@ -1322,8 +1386,8 @@ __global__ __launch_bounds__(Geo<PART>::kWaves * 64, 4) void rx512_kernel(const 
   #pragma unroll
             for (int k = 0; k < 8; ++k) z[k] *= splat(amp[k]);
           }
-          // base phasor of my 8 samples from the 64-bit phase: 8-bit table entry (requested one
-          // sub-block ahead, so its L2 round trip is hidden) x 32-bit Taylor remainder
+          // base phasor of my 8 samples from the 64-bit phase: 8-bit table entry (requested at the
+          // top of the frame, see there) x 32-bit Taylor remainder
           cf base;
           {
             const uint64_t P = phase0 + (uint64_t)(n0 + 1) * dphi;
@@ -1332,11 +1396,12 @@ __global__ __launch_bounds__(Geo<PART>::kWaves * 64, 4) void rx512_kernel(const 
             const float a2 = ang * ang;
             const float sn = ang * fmaf(a2, -1.0f / 6.0f, 1.0f);
             const float cs = fmaf(a2, fmaf(a2, 1.0f / 24.0f, -0.5f), 1.0f);
-            base = cmul(cf{osc_tab.x, osc_tab.y}, cf{cs, sn});
-            if (s < 3) {
-              const uint64_t Pn = P + (uint64_t)512 * dphi;
-              osc_tab = (PART == 1) ? reinterpret_cast<const float2 *>(smem)[(int)(Pn >> 56)] : tab[kTabSinCos + (int)(Pn >> 56)];
-            }
+#if T41RX_OSC_TOP
+            base = cmul(cf{osc_tab[s].x, osc_tab[s].y}, cf{cs, sn});
+#else
+            const float2 t = (PART == 1) ? reinterpret_cast<const float2 *>(smem)[(int)(P >> 56)] : tab[kTabSinCos + (int)(P >> 56)];
+            base = cmul(cf{t.x, t.y}, cf{cs, sn});
+#endif
           }
           // -- Fs/4 shift (x j^n, Freq_Shift.cpp:42-65) and NCO mix (Freq_Shift.cpp:138-139):
           //    (I' + jQ') = (I + jQ) j^k conj(Osc_k) = (I + jQ) conj(base wk''),  wk'' = wk (-j)^k
@@ -1385,7 +1450,7 @@ __global__ __launch_bounds__(Geo<PART>::kWaves * 64, 4) void rx512_kernel(const 
             if (lane < 14) hh = lds4(lds + kX + 2 * xpad(512 + 2 * lane));
             wave_sync();
             if (lane < 14) *reinterpret_cast<float4 *>(lds + kX + 2 * xpad(2 * lane)) = hh;
-            *reinterpret_cast<float4 *>(lds + kY1 + 2 * (48 + 128 * h + 2 * lane)) =
+            *reinterpret_cast<float4 *>(lds + kY1 + y1slot(24 + 64 * h + lane)) =
                 make_float4(o1[0].x, o1[0].y, o1[1].x, o1[1].y);
           }
         }  // h
@@ -1395,33 +1460,35 @@ __global__ __launch_bounds__(Geo<PART>::kWaves * 64, 4) void rx512_kernel(const 
         wave_sync();
         // y[m] = sum_i c[i] * state[2m + i]; state[i] = buf[i + 3]
         {
-          auto lin = [](int o) { return o; };
+          // window-relative complex offset o (even) -> offset in the planes, relative to lds + kY1 + 4 lane
+          auto planes = [](int o) { return y1slot(o >> 1) / 2; };
           if (!T41RX_CUT(3)) {
-            fir_pair<kDec2Taps, 3, 5, 26, 6>(lds + kY1 + 8 * lane, lin, (CFloatPtr)cf0->dec2, y2[rd][0], y2[rd][1]);
+            fir_pair<kDec2Taps, 3, 5, 26, 6>(lds + kY1 + 4 * lane, planes, (CFloatPtr)cf0->dec2, y2[rd][0], y2[rd][1]);
           } else {
-            y2[rd][0] = *reinterpret_cast<cf *>(lds + kY1 + 8 * lane);
-            y2[rd][1] = *reinterpret_cast<cf *>(lds + kY1 + 8 * lane + 2);
+            y2[rd][0] = *reinterpret_cast<cf *>(lds + kY1 + 4 * lane);
+            y2[rd][1] = *reinterpret_cast<cf *>(lds + kY1 + 4 * lane + 2);
           }
         }
         STAMP(5);  // /2 decimator
       {  // roll the /2 history: logical 256..303 -> 0..47
           float4 hh = make_float4(0, 0, 0, 0);
-          if (lane < 24) hh = lds4(lds + kY1 + 2 * (256 + 2 * lane));
+          if (lane < 24) hh = lds4(lds + kY1 + y1slot(128 + lane));
           wave_sync();
-          if (lane < 24) *reinterpret_cast<float4 *>(lds + kY1 + 4 * lane) = hh;
+          if (lane < 24) *reinterpret_cast<float4 *>(lds + kY1 + y1slot(lane)) = hh;
         }
       }  // rd
       phase0 += (uint64_t)L * dphi;
       if (PART == 0 || (f & (seg - 1)) == seg - 1) dc_carry = uniform_f32(dc2.y);  // the shared biquad ends the frame on Q
 
       STAMP(4);
+      FRESH_LANE();
       // ---- !KEEP: delay lines back to HBM (the LDS copies are about to be reused as scratch).
       // Issue the small back-end loads now so the FFT hides their latency: interpolator histories,
       // the AGC record; KEEP: the filter mask of this lane (8 x 8 B from the L2-resident table).
       wave_sync();
       if (!KEEP) {
         if (lane < 14) *reinterpret_cast<float4 *>(st + kStDec1 + 4 * lane) = lds4(lds + kX + 2 * xpad(2 * lane));
-        if (lane < 24) *reinterpret_cast<float4 *>(st + kStDec2 + 4 * lane) = lds4(lds + kY1 + 4 * lane);
+        if (lane < 24) *reinterpret_cast<float4 *>(st + kStDec2 + 4 * lane) = lds4(lds + kY1 + y1slot(lane));
         if (PART != 1) {
           if (lane < 6) hist1 = *reinterpret_cast<const float4 *>(st + kStInt1 + 4 * lane);
           if (lane < 8) hist2 = st[kStInt2 + lane];
@@ -1538,11 +1605,13 @@ __global__ __launch_bounds__(Geo<PART>::kWaves * 64, 4) void rx512_kernel(const 
       }
 
       STAMP(6);  // state save, level, overlap-save assemble
+      FRESH_LANE();
       // ---- FFT, x mask, inverse FFT (Process.cpp:535-595).  The mask table is pre-scaled by 1/N.
       {
         cf tw1[7], tw2[7];
         cf mk[8];  // KEEP: FIR_filter_mask[lane + 64 r] / N, requested from the L2-resident table inside the forward FFT
-        if (!KEEP) {
+        constexpr bool GMASK = KEEP || T41RX_X_GMASK;
+        if (!GMASK) {
   #pragma unroll
           for (int q = 0; q < 7; ++q) {
             tw1[q] = ltab[G::kTw1 + 64 * q + lane];
@@ -1550,7 +1619,7 @@ __global__ __launch_bounds__(Geo<PART>::kWaves * 64, 4) void rx512_kernel(const 
           }
         }
         if (!T41RX_CUT(2)) {
-          if (KEEP) {
+          if (GMASK) {
             fft512_ldstw<false>(v, ltab + G::kTw1 + lane, ltab + G::kTw2 + (lane & 7), lds + kScr, lane, [&]() {
   #pragma unroll
               for (int r = 0; r < 8; ++r) {
@@ -1562,7 +1631,7 @@ __global__ __launch_bounds__(Geo<PART>::kWaves * 64, 4) void rx512_kernel(const 
             fft512<false>(v, tw1, tw2, lds + kScr, lane);
           }
   #pragma unroll
-          for (int r = 0; r < 8; ++r) v[r] = cmul(v[r], KEEP ? mk[r] : ltab[kLdsTabMask + 64 * r + lane]);
+          for (int r = 0; r < 8; ++r) v[r] = cmul(v[r], GMASK ? mk[r] : ltab[kLdsTabMask + 64 * r + lane]);
           if (DEBUG && a.spect) {
             // ---- audio spectrum side output (Process.cpp:550-570 with updateDisplayFlag == 1):
             // audioSpectBuffer[1023 - k] = iFFT_buffer[k]^2 over the 1024 floats of the masked
@@ -1596,13 +1665,14 @@ __global__ __launch_bounds__(Geo<PART>::kWaves * 64, 4) void rx512_kernel(const 
               st[kStMisc + kMiscMaxSqAve] = ave;
             }
           }
-          if (KEEP)
+          if (GMASK)
             fft512_ldstw<true>(v, ltab + G::kTw1 + lane, ltab + G::kTw2 + (lane & 7), lds + kScr, lane, []() {});
           else
             fft512<true>(v, tw1, tw2, lds + kScr, lane);
         }
       }
     }
+    FRESH_LANE();
     if (PART != 2 || LONGC) {
       // ---- AGC (Process.cpp:605 / :810).  Off: fixed gain on the valid half (DSP_Fn.cpp:494-502).
       // SSB/NFM: audio = Re
@@ -1753,9 +1823,12 @@ __global__ __launch_bounds__(Geo<PART>::kWaves * 64, 4) void rx512_kernel(const 
     if (T41RX_CUT(1)) {
 #pragma unroll
       for (int u = 0; u < 8; ++u)
-        *reinterpret_cast<float4 *>(gO + (T41RX_CUT(7) ? 4 * lane + 256 * u : 32 * lane + 4 * u)) = make_float4(aud[0], aud[1], aud[2], aud[3]);
+        *reinterpret_cast<float4 *>(gO + (T41RX_ABLATE == 8 ? 32 * (16 * (u & 3) + (lane >> 2)) + 16 * (u >> 2) + 4 * (lane & 3)
+                                          : T41RX_CUT(7)    ? 4 * lane + 256 * u
+                                                            : 32 * lane + 4 * u)) = make_float4(aud[0], aud[1], aud[2], aud[3]);
       continue;
     }
+    FRESH_LANE();
     // ---- interpolate by 2 (48 taps, phase length 24): inputs n = 4 lane .. 4 lane + 3
     // LDS buf: [0] pad, [1..23] history, [24 + i] new sample i
     wave_sync();
@@ -1806,6 +1879,7 @@ __global__ __launch_bounds__(Geo<PART>::kWaves * 64, 4) void rx512_kernel(const 
       }
     }
     STAMP(11);  // x2 interpolator
+    FRESH_LANE();
     // ---- interpolate by 4 (32 taps, phase length 8): inputs n = 8 lane .. 8 lane + 7; the
     // 7-sample history is the neighbouring lane's tail (lane 0: last frame's, from HBM)
     {
@@ -1841,7 +1915,24 @@ __global__ __launch_bounds__(Geo<PART>::kWaves * 64, 4) void rx512_kernel(const 
       // conflict-free both for these row writes and for the column reads below) ...
       wave_sync();
       unsigned qw[2] = {0u, 0u};  // WQ15: the four packed samples of the even u
-      float *tr = lds + kScr;
+      // KEEP, f32 samples: the transposition needs 2048 floats, more than the slice has free, so it
+      // takes the slice from its start and the resident state it covers waits in registers
+      // meanwhile: the /4 history (lanes 0..13) and the /2 history (lanes 16..39) share one
+      // float4, the part of the overlap block below float 2048 (lanes 0..22) takes another.
+      // (Two half-size transpositions instead -- 64-byte store segments -- cost 8..17 % of the
+      // whole kernel: measured, tools/variant_sweep.py nores_half.)
+      constexpr bool PARK = KEEP && !WQ15 && !T41RX_X_HALFTR;
+      constexpr int kOvPark = (2048 - G::kOV + 3) / 4;  // float4s of the overlap block below float 2048
+      static_assert(!PARK || (kOvPark > 0 && kOvPark <= 64 && G::kH1 >= 2048), "parking layout");
+      float4 park_h = make_float4(0, 0, 0, 0), park_o = make_float4(0, 0, 0, 0);
+      if (PARK) {
+        if (lane < 14) park_h = lds4(lds + kX + 2 * xpad(2 * lane));
+        else if (lane >= 16 && lane < 40) park_h = lds4(lds + kY1 + y1slot(lane - 16));
+        if (lane < kOvPark) park_o = lds4(lds + G::kOV + 4 * lane);
+        wave_sync();
+      }
+      float *tr = PARK ? lds : lds + kScr;
+      constexpr bool HALFTR = (KEEP && !PARK) || T41RX_X_HALFTR;
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         f2 o01 = splat(0.0f), o23 = splat(0.0f);
@@ -1854,19 +1945,19 @@ __global__ __launch_bounds__(Geo<PART>::kWaves * 64, 4) void rx512_kernel(const 
         // ---- volume (Process.cpp:929)
         o01 *= splat(out_scale);
         o23 *= splat(out_scale);
-        if (!WQ15 && !KEEP) {
+        if (!WQ15 && !HALFTR) {
           *reinterpret_cast<float4 *>(tr + 4 * (8 * lane + (u ^ (lane & 7)))) = make_float4(o01.x, o01.y, o23.x, o23.y);
         } else if (!WQ15) {
-          // KEEP: the transposition buffer is 1024 floats (the rest of the slice holds the channel's
-          // state), so the 32 outputs of a lane go out in two halves of 16 = 64 contiguous bytes per
-          // lane: slot 4 lane + ((u & 3) ^ swizzle), and a store instruction then writes 16 rows of 64 B
-          *reinterpret_cast<float4 *>(tr + 4 * (4 * lane + ((u & 3) ^ ((lane >> 2) & 3)))) = make_float4(o01.x, o01.y, o23.x, o23.y);
+          // (experiment T41RX_X_HALFTR) a 1024-float transposition buffer: the 32 outputs of a lane
+          // go out in two halves of 16 = 64 contiguous bytes per lane: slot 4 lane + ((u & 3) ^
+          // swizzle), swizzle = (lane >> 1) & 3, and a store instruction then writes 16 rows of 64 B
+          *reinterpret_cast<float4 *>(tr + 4 * (4 * lane + ((u & 3) ^ ((lane >> 1) & 3)))) = make_float4(o01.x, o01.y, o23.x, o23.y);
           if ((u & 3) == 3) {
             wave_sync();
 #pragma unroll
             for (int i = 0; i < 4; ++i) {  // float4 F = 64 i + lane of this half: row F >> 2, column F & 3
               const int row = 16 * i + (lane >> 2);
-              const float4 t = lds4(tr + 4 * (4 * row + ((lane & 3) ^ ((row >> 2) & 3))));
+              const float4 t = lds4(tr + 4 * (4 * row + ((lane & 3) ^ ((row >> 1) & 3))));
               stg_stream(gO + 32 * row + 16 * (u >> 2) + 4 * (lane & 3), t);
             }
             wave_sync();
@@ -1877,7 +1968,7 @@ __global__ __launch_bounds__(Geo<PART>::kWaves * 64, 4) void rx512_kernel(const 
         } else {
           // 8 samples = one 16-byte piece; a lane has 4 of them: slot 4 lane + (piece ^ swizzle)
           const int piece = u >> 1;
-          *reinterpret_cast<uint4 *>(tr + 4 * (4 * lane + (piece ^ ((lane >> 2) & 3)))) =
+          *reinterpret_cast<uint4 *>(tr + 4 * (4 * lane + (piece ^ ((lane >> 1) & 3)))) =
               make_uint4(qw[0], qw[1], q15_pack2(o01.x, o01.y), q15_pack2(o23.x, o23.y));
         }
       }
@@ -1885,7 +1976,7 @@ __global__ __launch_bounds__(Geo<PART>::kWaves * 64, 4) void rx512_kernel(const 
       STAMP(12);  // x4 interpolator + LDS transpose writes
       // ... and every global store instruction then writes 1 KiB of consecutive addresses:
       // float4 index F = 64 i + lane lives in row F >> 3 = 8 i + (lane >> 3), column lane & 7
-      if (!WQ15 && !KEEP) {
+      if (!WQ15 && !HALFTR) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const int row = 8 * i + (lane >> 3);
@@ -1896,9 +1987,15 @@ __global__ __launch_bounds__(Geo<PART>::kWaves * 64, 4) void rx512_kernel(const 
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int row = 16 * i + (lane >> 2);
-          const float4 t = lds4(tr + 4 * (4 * row + ((lane & 3) ^ ((row >> 2) & 3))));
+          const float4 t = lds4(tr + 4 * (4 * row + ((lane & 3) ^ ((row >> 1) & 3))));
           stg_stream(gO + 256 * i + 4 * lane, t);
         }
+      }
+      if (PARK) {  // the resident state returns to its place
+        wave_sync();
+        if (lane < 14) *reinterpret_cast<float4 *>(lds + kX + 2 * xpad(2 * lane)) = park_h;
+        else if (lane >= 16 && lane < 40) *reinterpret_cast<float4 *>(lds + kY1 + y1slot(lane - 16)) = park_h;
+        if (lane < kOvPark) *reinterpret_cast<float4 *>(lds + G::kOV + 4 * lane) = park_o;
       }
     }
     STAMP(13);  // transposed reads + global stores
@@ -1917,7 +2014,7 @@ __global__ __launch_bounds__(Geo<PART>::kWaves * 64, 4) void rx512_kernel(const 
   if (KEEP) {  // the channel's record goes back to HBM once per launch
     wave_sync();
     if (lane < 14) *reinterpret_cast<float4 *>(st + kStDec1 + 4 * lane) = lds4(lds + kX + 2 * xpad(2 * lane));
-    if (lane < 24) *reinterpret_cast<float4 *>(st + kStDec2 + 4 * lane) = lds4(lds + kY1 + 4 * lane);
+    if (lane < 24) *reinterpret_cast<float4 *>(st + kStDec2 + 4 * lane) = lds4(lds + kY1 + y1slot(lane));
     *reinterpret_cast<float4 *>(st + kStOverlap + 4 * lane) = lds4(lds + G::kOV + 4 * lane);
     *reinterpret_cast<float4 *>(st + kStOverlap + 256 + 4 * lane) = lds4(lds + G::kOV + 256 + 4 * lane);
     if (lane < 6) *reinterpret_cast<float4 *>(st + kStInt1 + 4 * lane) = lds4(lds + G::kH1 + 4 * lane);

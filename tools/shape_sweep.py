@@ -19,7 +19,7 @@ def run(nch, nfr, reps=200, ring=6):
     Is = [0.2 * torch.randn(nch, nfr * L, generator=g, device="cuda") for _ in range(ring)]
     Qs = [0.2 * torch.randn(nch, nfr * L, generator=g, device="cuda") for _ in range(ring)]
     out = [torch.empty(nch, nfr * L, device="cuda") for _ in range(ring)]
-    for k in range(10):
+    for k in range(max(10, reps // 4)):
         rx.ProcessIQData(Is[k % ring], Qs[k % ring], out=out[k % ring])
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -62,7 +62,7 @@ WORKLOADS = {
 }
 BYTES_PER_SAMPLE = 12.0     # 2 x f32 in + 1 x f32 out per input complex sample
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-DEFAULT_FRAMES = 16         # consecutive frames per channel per launch (>= 100 consecutive frames per run)
+DEFAULT_FRAMES = 32         # consecutive frames per channel per launch (>= 100 consecutive frames per run)
 KERNEL_SOURCES = ("t41_sdr_amd/csrc/rx_kernels.hip", "t41_sdr_amd/csrc/rx_kernels.hpp", "t41_sdr_amd/csrc/rx_internal.hpp")
 
 
@@ -225,9 +225,12 @@ def dry_run(args, world, rank):
     import torch.distributed as dist
     import t41_sdr_amd as T
     from t41_sdr_amd.dist import broadcast_coeffs, max_over_ranks, shard_channels
+    if os.environ.get("T41RX_BENCH_FAIL_RANK") == str(rank):  # test hook: one rank dies before the rendezvous
+        raise SystemExit(3)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo", world_size=world, rank=rank)
+        import datetime
+        dist.init_process_group(backend="gloo", world_size=world, rank=rank, timeout=datetime.timedelta(seconds=60))
     observed = dist.get_world_size() if world > 1 else 1
     if args.gpus != observed:
         raise SystemExit("--gpus %d but the process group has %d ranks" % (args.gpus, observed))

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define T41RX_ABI_VERSION 2
+#define T41RX_ABI_VERSION 3
 
 /* status codes */
 #define T41RX_OK 0
@@ -92,7 +92,8 @@ void t41rx_default_params(t41rx_params *p);
  * The arrays CalcFilters() (Filter.cpp:235-249), InitFilterMask() (Filter.cpp:260-284),
  * SetDecIntFilters() (Filter.cpp:396-438) and InitializeDataArrays() (T41_SDR.ino:560-566) leave
  * behind, serialised as one blob:
- *   header (8 x int32: magic, abi, fft_length, mode, 4 reserved) |
+ *   header (24 x int32: magic, abi, fft_length, mode, sizeof(t41rx_params), 3 reserved, then the
+ *   t41rx_params the blob was designed for, padded to 16 words) |
  *   FIR_dec1_coeffs[28] | FIR_dec2_coeffs[46] | FIR_int1_coeffs[48] | FIR_int2_coeffs[32] |
  *   biquad_lowpass1_coeffs[5] | scalars[11] | AGC constants[16] (what AGCPrep() +
  *   AGCLoadValues() leave behind, DSP_Fn.cpp:368-468; zeros for AGCMode 0) |
@@ -114,7 +115,9 @@ int t41rx_set_params(t41rx_ctx *ctx, const t41rx_params *p);
 int t41rx_get_params(const t41rx_ctx *ctx, t41rx_params *p);
 
 /* Coefficient blob of the context (see t41rx_design_coeffs).  set = install a blob designed
- * elsewhere (e.g. received by broadcast); it must match the context's fft_length. */
+ * elsewhere (e.g. received by broadcast); it must match the context's fft_length.  The context
+ * takes over the parameters stored in the blob (mode, AGCMode, cut-offs, gains ...), so afterwards
+ * t41rx_get_params() returns the designer's and a later t41rx_set_params() starts from them. */
 int t41rx_get_coeffs(const t41rx_ctx *ctx, void *blob, size_t blob_bytes);
 int t41rx_set_coeffs(t41rx_ctx *ctx, const void *blob, size_t blob_bytes);
 
@@ -153,7 +156,10 @@ int t41rx_process_device_q15(t41rx_ctx *ctx, const int16_t *dQ_in_L, const int16
 int t41rx_process_host_q15(t41rx_ctx *ctx, const int16_t *Q_in_L, const int16_t *Q_in_R,
                            int16_t *Q_out_L, int n_frames);
 
-/* ---- checkpoint of the streaming state (the reference never persists it) ---- */
+/* ---- checkpoint of the streaming state (the reference never persists it) ----
+ * The buffer starts with a 32-byte header (magic, abi, fft_length, n_channels, floats per channel,
+ * 3 reserved); t41rx_set_state() refuses (T41RX_ERR_STATE) a checkpoint of another ABI, FFT length
+ * or channel count, and one whose AGC state words or oscillator amplitude are out of range. */
 size_t t41rx_state_bytes(const t41rx_ctx *ctx);
 int    t41rx_get_state(t41rx_ctx *ctx, void *host_buf, size_t bytes);
 int    t41rx_set_state(t41rx_ctx *ctx, const void *host_buf, size_t bytes);
@@ -162,8 +168,10 @@ int    t41rx_set_state(t41rx_ctx *ctx, const void *host_buf, size_t bytes);
  * When set, the next process calls also write, per channel and frame:
  *   post_nco : [n_channels][n_frames*frame_len*2]  I/Q after FreqShift2 (planar: I then Q per frame)
  *   dec      : [n_channels][n_frames*fft_length]   I/Q after decimate-by-8 (+ level adjust)
- *   demod    : [n_channels][n_frames*fft_length/2] audio @24 kS/s before interpolation */
-int t41rx_set_debug_taps(t41rx_ctx *ctx, float *d_post_nco, float *d_dec, float *d_demod);
+ *   demod    : [n_channels][n_frames*fft_length/2] audio @24 kS/s before interpolation
+ * max_frames = the n_frames the buffers are sized for: a process call with more frames is refused
+ * (T41RX_ERR_ARG) instead of writing past them.  fft_length 512 only (T41RX_ERR_UNSUPPORTED). */
+int t41rx_set_debug_taps(t41rx_ctx *ctx, float *d_post_nco, float *d_dec, float *d_demod, int max_frames);
 
 /* ---- the path's display by-product: the audio spectrum and the S-meter's input ----
  * What ProcessIQData() leaves behind when updateDisplayFlag == 1 (Process.cpp:550-570; NFM:
@@ -174,8 +182,8 @@ int t41rx_set_debug_taps(t41rx_ctx *ctx, float *d_post_nco, float *d_dec, float 
  *   d_spect : [n_channels][n_frames][1024]  audioSpectBuffer
  *   d_max   : [n_channels][n_frames][3]     audioMaxSquared, (float)AudioMaxIndex, audioMaxSquaredAve
  * and updates the per-channel audioMaxSquaredAve.  The pixel mapping (audioYPixel) is display
- * code and stays with the caller.  fft_length 512, f32 entry points only. */
-int t41rx_set_audio_spectrum(t41rx_ctx *ctx, float *d_spect, float *d_max);
+ * code and stays with the caller.  fft_length 512, f32 entry points only.  max_frames as above. */
+int t41rx_set_audio_spectrum(t41rx_ctx *ctx, float *d_spect, float *d_max, int max_frames);
 
 #ifdef __cplusplus
 }

@@ -58,13 +58,13 @@ SYMBOLS = {
     "t41rx_frame_len": (C.c_int, [_vp]),
     "t41rx_process_device": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp]),
     "t41rx_process_host": (C.c_int, [_vp, _fp, _fp, _fp, C.c_int]),
-    "t41rx_set_audio_spectrum": (C.c_int, [_vp, _vp, _vp]),
+    "t41rx_set_audio_spectrum": (C.c_int, [_vp, _vp, _vp, C.c_int]),
     "t41rx_process_device_q15": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp]),
     "t41rx_process_host_q15": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int]),
     "t41rx_state_bytes": (C.c_size_t, [_vp]),
     "t41rx_get_state": (C.c_int, [_vp, _vp, C.c_size_t]),
     "t41rx_set_state": (C.c_int, [_vp, _vp, C.c_size_t]),
-    "t41rx_set_debug_taps": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "t41rx_set_debug_taps": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int]),
 }
 
 _lib = None

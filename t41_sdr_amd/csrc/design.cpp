@@ -225,6 +225,8 @@ int design_blob(const t41rx_params &p, void *blob, size_t blob_bytes) {
   v.header[1] = T41RX_ABI_VERSION;
   v.header[2] = N;
   v.header[3] = p.mode;
+  v.header[4] = (int32_t)sizeof(t41rx_params);
+  std::memcpy(v.header + 8, &p, sizeof(t41rx_params));
 
   // --- filter mask: (N/2+1)-tap complex band-pass at 24 kS/s, zero-padded, FFT'd ---
   const int ntaps = N / 2 + 1;  // m_NumTaps, Filter.cpp:18

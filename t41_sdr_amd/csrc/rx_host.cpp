@@ -10,7 +10,6 @@
 
 #include <cmath>
 #include <cstdio>
-#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -33,11 +32,11 @@ struct t41rx_ctx {
   ChanNco *d_nco = nullptr;
   float *dbg_nco = nullptr, *dbg_dec = nullptr, *dbg_demod = nullptr;
   float *spect = nullptr, *spect_max = nullptr;  // audio-spectrum side output (t41rx_set_audio_spectrum)
+  int tap_frames = 0, spect_frames = 0;          // frames per call those buffers are sized for
   // FFT_LENGTH 4096 pipeline: constant table + scratch between its three kernels
   float2 *d_tab4k = nullptr;
   float *d_mid = nullptr, *d_aud24 = nullptr;
   int scratch_frames = 0;
-  int stagger = 0;               // launch tuning: see RxArgs::stagger (env T41RX_STAGGER overrides)
   // staging for t41rx_process_host
   float *d_in_i = nullptr, *d_in_q = nullptr, *d_out = nullptr;
   size_t staging_floats = 0;
@@ -306,7 +305,6 @@ int t41rx_create(t41rx_ctx **out, int device_id, int n_channels, const t41rx_par
   ctx->device = device_id;
   ctx->nchan = n_channels;
   ctx->params = *p;
-  if (const char *e = std::getenv("T41RX_STAGGER")) ctx->stagger = std::atoi(e);
   ctx->blob.assign(blob_floats(p->fft_length), 0.0f);
   ctx->nco_hz.assign((size_t)n_channels, 0);
   int rc = design_blob(*p, ctx->blob.data(), ctx->blob.size() * sizeof(float));
@@ -381,11 +379,19 @@ int t41rx_set_coeffs(t41rx_ctx *ctx, const void *blob, size_t blob_bytes) {
   if ((uint32_t)h[0] != kBlobMagic || h[1] != T41RX_ABI_VERSION) return fail(T41RX_ERR_STATE, "bad blob header");
   if (h[2] != ctx->params.fft_length) return fail(T41RX_ERR_STATE, "blob fft_length differs from the context");
   if (h[3] < T41RX_DEMOD_USB || h[3] > T41RX_DEMOD_NFM) return fail(T41RX_ERR_STATE, "bad demodulation mode in blob");
+  // the parameters the blob was designed for become the context's (every rank that installs a
+  // broadcast blob then runs -- and later re-designs from -- the designer's parameters)
+  if (h[4] != (int32_t)sizeof(t41rx_params)) return fail(T41RX_ERR_STATE, "blob carries another t41rx_params layout");
+  t41rx_params bp;
+  std::memcpy(&bp, h + 8, sizeof(bp));
+  const char *why = nullptr;
+  if (!params_valid(bp, &why) || bp.fft_length != h[2] || bp.mode != h[3])
+    return fail(T41RX_ERR_STATE, std::string("blob parameters invalid: ") + (why ? why : "header mismatch"));
 
   DeviceGuard g(ctx->device);
   HIP_TRY(hipDeviceSynchronize());
   std::memcpy(ctx->blob.data(), blob, need);
-  ctx->params.mode = h[3];
+  ctx->params = bp;
   int rc = upload_coeffs(ctx);
   if (rc != T41RX_OK) return rc;
   return upload_nco(ctx);
@@ -478,13 +484,18 @@ int process_device_impl(t41rx_ctx *ctx, const float *dI, const float *dQ, float 
     a.neg_iq_amp = sc[kScNegIqAmp];
     a.iq_phase = sc[kScIqPhase];
     a.iq_corr_on = iq_on ? 1 : 0;
-    a.plain = ((gi == 1.0f || (iq_on && gi == -1.0f)) && sc[kScBandGain] == 1.0f && (!iq_on || sc[kScIqPhase] == 0.0f)) ? 1 : 0;
+    // PLAIN folds "I <- -I" (IQ correction on, amplitude factor 1) into the sign of the RF gain; with
+    // the correction on and gi = +1 (IQAmpCorrectionFactor = -1) the general kernel must run
+    a.plain = ((iq_on ? gi == -1.0f : gi == 1.0f) && sc[kScBandGain] == 1.0f && (!iq_on || sc[kScIqPhase] == 0.0f)) ? 1 : 0;
   }
   a.q15 = q15 ? 1 : 0;
-  a.stagger = (n_frames >= 4) ? ctx->stagger : 0;  // pays only when a launch runs several frames
   a.agc = ctx->params.AGCMode != 0 ? 1 : 0;
   if (a.agc && (int)blob_view(ctx->blob.data()).agc[kAgcAttackBuffsize] != kAgcDelay)
     return fail(T41RX_ERR_STATE, "coefficient blob carries an AGC look-ahead the kernel is not built for");
+  if ((ctx->dbg_nco || ctx->dbg_dec || ctx->dbg_demod) && n_frames > ctx->tap_frames)
+    return fail(T41RX_ERR_ARG, "n_frames exceeds the max_frames the debug tap buffers were set with");
+  if (ctx->spect && n_frames > ctx->spect_frames)
+    return fail(T41RX_ERR_ARG, "n_frames exceeds the max_frames the audio-spectrum buffers were set with");
   a.dbg_nco = ctx->dbg_nco;
   a.dbg_dec = ctx->dbg_dec;
   a.dbg_demod = ctx->dbg_demod;
@@ -549,9 +560,14 @@ int t41rx_process_host(t41rx_ctx *ctx, const float *I, const float *Q, float *au
   return T41RX_OK;
 }
 
+namespace {
+constexpr uint32_t kStateMagic = 0x54343153u;  // "T41S"
+constexpr size_t kStateHeaderBytes = 32;
+}  // namespace
+
 size_t t41rx_state_bytes(const t41rx_ctx *ctx) {
   if (!ctx) return 0;
-  return sizeof(float) * state_floats(ctx->params.fft_length) * (size_t)ctx->nchan;
+  return kStateHeaderBytes + sizeof(float) * state_floats(ctx->params.fft_length) * (size_t)ctx->nchan;
 }
 
 int t41rx_get_state(t41rx_ctx *ctx, void *host_buf, size_t bytes) {
@@ -559,35 +575,66 @@ int t41rx_get_state(t41rx_ctx *ctx, void *host_buf, size_t bytes) {
   if (bytes < t41rx_state_bytes(ctx)) return fail(T41RX_ERR_STATE, "state buffer too small");
   DeviceGuard g(ctx->device);
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(host_buf, ctx->d_state, t41rx_state_bytes(ctx), hipMemcpyDeviceToHost));
+  int32_t hdr[8] = {(int32_t)kStateMagic, T41RX_ABI_VERSION, ctx->params.fft_length, ctx->nchan,
+                    (int32_t)state_floats(ctx->params.fft_length), 0, 0, 0};
+  std::memcpy(host_buf, hdr, sizeof(hdr));
+  HIP_TRY(hipMemcpy(static_cast<char *>(host_buf) + kStateHeaderBytes, ctx->d_state,
+                    t41rx_state_bytes(ctx) - kStateHeaderBytes, hipMemcpyDeviceToHost));
   return T41RX_OK;
 }
 
 int t41rx_set_state(t41rx_ctx *ctx, const void *host_buf, size_t bytes) {
   if (!ctx || !host_buf) return fail(T41RX_ERR_ARG, "null argument");
   if (bytes != t41rx_state_bytes(ctx)) return fail(T41RX_ERR_STATE, "state size mismatch");
+  int32_t hdr[8];
+  std::memcpy(hdr, host_buf, sizeof(hdr));
+  const size_t sf = state_floats(ctx->params.fft_length);
+  if ((uint32_t)hdr[0] != kStateMagic || hdr[1] != T41RX_ABI_VERSION || hdr[2] != ctx->params.fft_length ||
+      hdr[3] != ctx->nchan || hdr[4] != (int32_t)sf)
+    return fail(T41RX_ERR_STATE, "checkpoint header does not match this context (magic / abi / fft_length / channels)");
+  // what the kernels consume as it stands: the oscillator amplitude and the AGC state words
+  const float *rec = reinterpret_cast<const float *>(static_cast<const char *>(host_buf) + kStateHeaderBytes);
+  const size_t ag = st_agc(ctx->params.fft_length) + kAgcHistFloats;
+  for (int c = 0; c < ctx->nchan; ++c) {
+    const float *r = rec + sf * (size_t)c;
+    NcoState ns;
+    std::memcpy(&ns, r + kStNco, sizeof(ns));
+    if (!(ns.r > 0.25 && ns.r < 4.0)) return fail(T41RX_ERR_STATE, "checkpoint: oscillator amplitude out of range");
+    int32_t w[3];
+    std::memcpy(w, r + ag + kAgcStState, sizeof(w));
+    if (w[0] < 0 || w[0] > 4 || w[1] < 0 || w[1] > 1 || w[2] < 0 || w[2] > (1 << 20))
+      return fail(T41RX_ERR_STATE, "checkpoint: AGC state words out of range");
+    for (int k = 0; k < 4; ++k)
+      if (!std::isfinite(r[ag + k])) return fail(T41RX_ERR_STATE, "checkpoint: AGC levels not finite");
+  }
   DeviceGuard g(ctx->device);
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(ctx->d_state, host_buf, bytes, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(ctx->d_state, rec, bytes - kStateHeaderBytes, hipMemcpyHostToDevice));
   return T41RX_OK;
 }
 
-int t41rx_set_debug_taps(t41rx_ctx *ctx, float *d_post_nco, float *d_dec, float *d_demod) {
+int t41rx_set_debug_taps(t41rx_ctx *ctx, float *d_post_nco, float *d_dec, float *d_demod, int max_frames) {
   if (!ctx) return fail(T41RX_ERR_ARG, "null argument");
+  const bool any = d_post_nco || d_dec || d_demod;
+  if (any && ctx->params.fft_length != 512) return fail(T41RX_ERR_UNSUPPORTED, "the stage taps are built for fft_length 512");
+  if (any && max_frames <= 0) return fail(T41RX_ERR_ARG, "max_frames must be > 0");
   ctx->dbg_nco = d_post_nco;
   ctx->dbg_dec = d_dec;
   ctx->dbg_demod = d_demod;
+  ctx->tap_frames = any ? max_frames : 0;
   return T41RX_OK;
 }
 
-}  // extern "C"
-
-int t41rx_set_audio_spectrum(t41rx_ctx *ctx, float *d_spect, float *d_max) {
+int t41rx_set_audio_spectrum(t41rx_ctx *ctx, float *d_spect, float *d_max, int max_frames) {
   if (!ctx) return fail(T41RX_ERR_ARG, "null context");
   if ((d_spect == nullptr) != (d_max == nullptr)) return fail(T41RX_ERR_ARG, "set both pointers or neither");
   if (d_spect && ctx->params.fft_length != 512) return fail(T41RX_ERR_UNSUPPORTED, "the audio spectrum is built for fft_length 512");
   if ((reinterpret_cast<uintptr_t>(d_spect) | reinterpret_cast<uintptr_t>(d_max)) & 3u) return fail(T41RX_ERR_ARG, "unaligned pointer");
+  if (d_spect && max_frames <= 0) return fail(T41RX_ERR_ARG, "max_frames must be > 0");
   ctx->spect = d_spect;
   ctx->spect_max = d_max;
+  ctx->spect_frames = d_spect ? max_frames : 0;
   return T41RX_OK;
 }
+
+}  // extern "C"

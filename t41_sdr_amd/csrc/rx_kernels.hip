@@ -70,34 +70,22 @@ __device__ __forceinline__ void wave_sync() {
 #ifndef T41RX_PF
 #define T41RX_PF 2
 #endif
-#ifndef T41RX_OSC_TOP
-#define T41RX_OSC_TOP 1  // 0 (experiments): oscillator table lookup at the point of use, inside the sub-block
-#endif
+
 // Issue priority falls as a wave advances through its frame (3: loads, mixer, decimators; 2:
 // FFTs and demodulator; 0: interpolators and stores), so the waves sharing a SIMD progress evenly
 // instead of oldest-first, which left each SIMD with one or two latency-bound waves for the last
 // third of the launch (per-wave end times from the -DT41RX_STAMP build: 24 .. 35 us within every
 // CU).  Measured: 33.8 -> 31.6 us; eight other schedules tried, rising priorities lose 0.2 us.
-// T41RX_PRIO_MODE (experiments): 0 = the schedule above; 1 = no priorities; 2 = one priority per
-// (wave, frame), rotating, so that the waves sharing a SIMD take turns at every level
-#ifndef T41RX_PRIO_MODE
-#define T41RX_PRIO_MODE 0
-#endif
-#if T41RX_PRIO_MODE == 0
+// (Multi-frame launches, measured: no priorities at all +1.5 %, a priority per (wave, frame)
+// rotating over the waves of a SIMD +0.5 %, start offsets between the waves of a CU up to a whole
+// frame period +-0.5 %: the waves spread over the frame by themselves within a few frames.)
 #define PRIO(n) __builtin_amdgcn_s_setprio(n)
-#else
-#define PRIO(n) do {} while (0)
-#endif
 #ifndef T41RX_FRESH
 #define T41RX_FRESH 1
 #endif
-// bisection experiments on the non-resident geometry: the resident kernel's output transposition
-// (two halves, 64-byte store segments) / its FFT (twiddles at use, mask from the global table)
+// experiment: a 1024-float output transposition in two halves (64-byte store segments)
 #ifndef T41RX_X_HALFTR
 #define T41RX_X_HALFTR 0
-#endif
-#ifndef T41RX_X_GMASK
-#define T41RX_X_GMASK 0
 #endif
 #if T41RX_FRESH
 #define FRESH_LANE() asm volatile("" : "+v"(lane))
@@ -1086,14 +1074,6 @@ __global__ __launch_bounds__(Geo<PART>::kWaves * 64, 4) void rx512_kernel(const 
   for (int f = 0; f < a.nframes; ++f) {
     PRIO(3);
     FRESH_LANE();
-#if T41RX_PRIO_MODE == 2
-    switch (((wv >> 2) + f) & 3) {
-      case 0: __builtin_amdgcn_s_setprio(0); break;
-      case 1: __builtin_amdgcn_s_setprio(1); break;
-      case 2: __builtin_amdgcn_s_setprio(2); break;
-      default: __builtin_amdgcn_s_setprio(3); break;
-    }
-#endif
     const size_t fbase = ((size_t)(T41RX_ABLATE == 9 ? (ch & 15) : ch) * a.nframes + f) * L;
     // (WQ15: two samples per float slot, so sample offsets halve)
     const float *__restrict__ gI = a.I + (WQ15 ? fbase / 2 : fbase);
@@ -1198,18 +1178,7 @@ __global__ __launch_bounds__(Geo<PART>::kWaves * 64, 4) void rx512_kernel(const 
         }
       }
       STAMP(16);  // prologue a: issue + scalar (SMEM) gains
-      if (f == 0) {
-        stage_tables();
-        if (KEEP && a.stagger > 0) {
-          // De-synchronise the 16 waves of the CU for the rest of the launch: wave w starts its
-          // first frame order(w) * stagger * 64 cycles late, order = 4 (w / 4) + (w % 4) (waves w,
-          // w + 4, ... share a SIMD).  Waves that move through the frame in step all load, then all
-          // compute, then all store; spread over the frame period, one wave's loads and stores run
-          // under the arithmetic of the others.
-          const int order = ((wv >> 2) << 2) | (wv & 3);
-          for (int i = 0; i < order * a.stagger; i += 16) __builtin_amdgcn_s_sleep(16);
-        }
-      }
+      if (f == 0) stage_tables();
       STAMP(17);  // prologue b: table staging + workgroup barrier (first vmcnt wait)
       if (!WQ15) {
         if (!carried1) {
@@ -1271,14 +1240,12 @@ __global__ __launch_bounds__(Geo<PART>::kWaves * 64, 4) void rx512_kernel(const 
       // are requested HERE and nowhere later: vector-memory results return in issue order, so a
       // table read issued between two input requests could only be used once every older input
       // request has landed -- it would cut the two-sub-block prefetch distance to nothing.
-#if T41RX_OSC_TOP
       float2 osc_tab[4];
   #pragma unroll
       for (int sb = 0; sb < 4; ++sb) {
         const uint64_t P = phase0 + (uint64_t)(512 * sb + 8 * lane + 1) * dphi;
         osc_tab[sb] = (PART == 1) ? reinterpret_cast<const float2 *>(smem)[(int)(P >> 56)] : tab[kTabSinCos + (int)(P >> 56)];
       }
-#endif
 
   #pragma unroll
       for (int rd = 0; rd < 2; ++rd) {
@@ -1396,12 +1363,7 @@ __global__ __launch_bounds__(Geo<PART>::kWaves * 64, 4) void rx512_kernel(const 
             const float a2 = ang * ang;
             const float sn = ang * fmaf(a2, -1.0f / 6.0f, 1.0f);
             const float cs = fmaf(a2, fmaf(a2, 1.0f / 24.0f, -0.5f), 1.0f);
-#if T41RX_OSC_TOP
             base = cmul(cf{osc_tab[s].x, osc_tab[s].y}, cf{cs, sn});
-#else
-            const float2 t = (PART == 1) ? reinterpret_cast<const float2 *>(smem)[(int)(P >> 56)] : tab[kTabSinCos + (int)(P >> 56)];
-            base = cmul(cf{t.x, t.y}, cf{cs, sn});
-#endif
           }
           // -- Fs/4 shift (x j^n, Freq_Shift.cpp:42-65) and NCO mix (Freq_Shift.cpp:138-139):
           //    (I' + jQ') = (I + jQ) j^k conj(Osc_k) = (I + jQ) conj(base wk''),  wk'' = wk (-j)^k
@@ -1610,7 +1572,7 @@ __global__ __launch_bounds__(Geo<PART>::kWaves * 64, 4) void rx512_kernel(const 
       {
         cf tw1[7], tw2[7];
         cf mk[8];  // KEEP: FIR_filter_mask[lane + 64 r] / N, requested from the L2-resident table inside the forward FFT
-        constexpr bool GMASK = KEEP || T41RX_X_GMASK;
+        constexpr bool GMASK = KEEP;  // (on the 4-wave geometry, measured: +1.2 .. 2.5 % against mask and twiddles in LDS / registers)
         if (!GMASK) {
   #pragma unroll
           for (int q = 0; q < 7; ++q) {

@@ -56,7 +56,6 @@ struct RxArgs {
   float iq_phase;          // sc[kScIqPhase]
   int iq_corr_on;          // sc[kScIqCorrOn] != 0
   int q15;                 // 1: I, Q, out point at int16 (q15) samples instead of f32 (Process.cpp:102-111, 936)
-  int stagger;             // fused 512 kernel: start offset between the waves of a CU, in units of 64 cycles (0 = none)
 };
 
 // constant table of the N = 512 R point fast convolution (float2 units):

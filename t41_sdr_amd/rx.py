@@ -39,10 +39,22 @@ def design_coeffs(params):
     return blob
 
 
+BLOB_HEADER_WORDS = 24   # magic, abi, fft_length, mode, sizeof(params), 3 reserved | t41rx_params padded to 16 words
+STATE_HEADER_BYTES = 32  # checkpoint header: magic, abi, fft_length, n_channels, floats per channel, 3 reserved
+
+
+def blob_params(blob):
+    """the t41rx_params a coefficient blob was designed for (what set_coeffs() installs)"""
+    p = Params()
+    raw = np.ascontiguousarray(blob, dtype=np.uint8)[4 * 8:4 * 8 + C.sizeof(Params)].tobytes()
+    C.memmove(C.byref(p), raw, C.sizeof(Params))
+    return p
+
+
 def blob_fields(blob, fft_length):
     """Split a coefficient blob into the reference's arrays (numpy views)."""
     f = np.frombuffer(blob, dtype=np.float32)
-    o = 8
+    o = BLOB_HEADER_WORDS
     out = {}
     for name, n in (("dec1", 28), ("dec2", 46), ("int1", 48), ("int2", 32), ("biquad_lowpass1", 5),
                     ("scalars", 11), ("agc", 16), ("mask", 2 * fft_length)):
@@ -109,6 +121,11 @@ class RxChain:
         buf = np.ascontiguousarray(buf, dtype=np.uint8)
         check(self._lib.t41rx_set_state(self._ctx, buf.ctypes.data_as(C.c_void_p), buf.size))
 
+    def state_records(self, buf=None):
+        """the per-channel records of a checkpoint (default: a fresh one) as float32 [n_channels, floats]"""
+        buf = self.get_state() if buf is None else np.ascontiguousarray(buf, dtype=np.uint8)
+        return buf[STATE_HEADER_BYTES:].view(np.float32).reshape(self.n_channels, -1)
+
     # -- the hot path ----------------------------------------------------------------------
     def ProcessIQData(self, float_buffer_L, float_buffer_R, out=None):
         """One ProcessIQData() per channel (or several consecutive ones).
@@ -121,7 +138,7 @@ class RxChain:
             I = np.ascontiguousarray(float_buffer_L, dtype=np.float32)
             Q = np.ascontiguousarray(float_buffer_R, dtype=np.float32)
             nfr = self._check_shape(I.shape, Q.shape)
-            audio = np.empty_like(I) if out is None else out
+            audio = np.empty_like(I) if out is None else self._check_out_numpy(out, I)
             fp = C.POINTER(C.c_float)
             check(self._lib.t41rx_process_host(self._ctx, I.ctypes.data_as(fp), Q.ctypes.data_as(fp),
                                                audio.ctypes.data_as(fp), nfr))
@@ -134,7 +151,7 @@ class RxChain:
         if I.device.index != self.device or Q.device.index != self.device:
             raise ValueError("I/Q live on another device than this RxChain")
         nfr = self._check_shape(tuple(I.shape), tuple(Q.shape))
-        audio = torch.empty_like(I) if out is None else out
+        audio = torch.empty_like(I) if out is None else self._check_out_torch(out, I)
         stream = torch.cuda.current_stream(I.device).cuda_stream
         check(self._lib.t41rx_process_device(self._ctx, I.data_ptr(), Q.data_ptr(), audio.data_ptr(), nfr,
                                              C.c_void_p(stream)))
@@ -149,7 +166,7 @@ class RxChain:
             a = np.ascontiguousarray(Q_in_L, dtype=np.int16)
             b = np.ascontiguousarray(Q_in_R, dtype=np.int16)
             nfr = self._check_shape(a.shape, b.shape)
-            audio = np.empty_like(a) if out is None else out
+            audio = np.empty_like(a) if out is None else self._check_out_numpy(out, a)
             check(self._lib.t41rx_process_host_q15(self._ctx, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p),
                                                    audio.ctypes.data_as(C.c_void_p), nfr))
             return audio
@@ -161,23 +178,56 @@ class RxChain:
         if a.device.index != self.device or b.device.index != self.device:
             raise ValueError("the queues live on another device than this RxChain")
         nfr = self._check_shape(tuple(a.shape), tuple(b.shape))
-        audio = torch.empty_like(a) if out is None else out
+        audio = torch.empty_like(a) if out is None else self._check_out_torch(out, a)
         stream = torch.cuda.current_stream(a.device).cuda_stream
         check(self._lib.t41rx_process_device_q15(self._ctx, a.data_ptr(), b.data_ptr(), audio.data_ptr(), nfr,
                                                  C.c_void_p(stream)))
         return audio
 
+    def _side_tensor(self, t, per_frame, what):
+        """validate a side-output tensor; returns (pointer, frames it has room for)"""
+        if t is None:
+            return None, None
+        import torch
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.device.index == self.device):
+            raise ValueError("%s must be a contiguous float32 CUDA tensor on device %d" % (what, self.device))
+        frames = t.numel() // (self.n_channels * per_frame)
+        if frames < 1:
+            raise ValueError("%s holds less than one frame (%d floats per channel and frame)" % (what, per_frame))
+        return C.c_void_p(t.data_ptr()), frames
+
     def set_debug_taps(self, post_nco=None, dec=None, demod=None):
-        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
-        check(self._lib.t41rx_set_debug_taps(self._ctx, ptr(post_nco), ptr(dec), ptr(demod)))
+        """stage taps (torch CUDA float32 tensors or None): post_nco [n_channels, n_frames*2*frame_len],
+        dec [n_channels, n_frames*fft_length], demod [n_channels, n_frames*fft_length/2].  Calls with
+        more frames than the smallest of them holds are refused."""
+        N = self.params.fft_length
+        got = [self._side_tensor(post_nco, 2 * self.frame_len, "post_nco"), self._side_tensor(dec, N, "dec"),
+               self._side_tensor(demod, N // 2, "demod")]
+        frames = [f for _, f in got if f is not None]
+        check(self._lib.t41rx_set_debug_taps(self._ctx, got[0][0], got[1][0], got[2][0], min(frames) if frames else 0))
         self._taps = (post_nco, dec, demod)  # keep alive
 
     def set_audio_spectrum(self, spect=None, maxima=None):
         """the display by-product of the path (Process.cpp:550-570): torch CUDA float32 tensors
         [n_channels, n_frames, 1024] and [n_channels, n_frames, 3], or None/None to switch it off"""
-        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
-        check(self._lib.t41rx_set_audio_spectrum(self._ctx, ptr(spect), ptr(maxima)))
+        ps, fs = self._side_tensor(spect, 1024, "spect")
+        pm, fm = self._side_tensor(maxima, 3, "maxima")
+        frames = [f for f in (fs, fm) if f is not None]
+        check(self._lib.t41rx_set_audio_spectrum(self._ctx, ps, pm, min(frames) if frames else 0))
         self._spect = (spect, maxima)  # keep alive
+
+    def _check_out_torch(self, out, like):
+        if not (out.is_cuda and out.dtype == like.dtype and out.is_contiguous() and tuple(out.shape) == tuple(like.shape)
+                and out.device == like.device):
+            raise ValueError("out must be a contiguous %s CUDA tensor of shape %r on %s" % (like.dtype, tuple(like.shape), like.device))
+        return out
+
+    @staticmethod
+    def _check_out_numpy(out, like):
+        if not (isinstance(out, np.ndarray) and out.dtype == like.dtype and out.shape == like.shape
+                and out.flags["C_CONTIGUOUS"] and out.flags["WRITEABLE"]):
+            raise ValueError("out must be a writeable C-contiguous %s array of shape %r" % (like.dtype, like.shape))
+        return out
 
     def _check_shape(self, si, sq):
         if si != sq or len(si) != 2 or si[0] != self.n_channels or si[1] == 0 or si[1] % self.frame_len:

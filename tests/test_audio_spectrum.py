@@ -56,7 +56,7 @@ def test_gpu_audio_spectrum(built, kw):
             assert mx[c, f, 0] == sp[c, f].max() and gi == int(np.argmax(sp[c, f]))  # self-consistent, first occurrence
     # switching it off returns to the plain kernels and leaves the running average alone
     rx.set_audio_spectrum(None, None)
-    before = rx.get_state().view(np.float32).reshape(nch, -1)[:, 184 + 12].copy()
+    before = rx.state_records()[:, 184 + 12].copy()
     rx.ProcessIQData(torch.from_numpy(I[:, :L].copy()).cuda(), torch.from_numpy(Q[:, :L].copy()).cuda())
-    after = rx.get_state().view(np.float32).reshape(nch, -1)[:, 184 + 12]
+    after = rx.state_records()[:, 184 + 12]
     assert np.array_equal(before, after) and np.all(before > 0)

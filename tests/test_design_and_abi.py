@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported(T):
     assert not missing, "declared in include/t41rx.h but not exported: %s" % missing
     from t41_sdr_amd import _lib
     assert declared == set(_lib.SYMBOLS), "python binding and header disagree"
-    assert lib.t41rx_abi_version() == 2
+    assert lib.t41rx_abi_version() == 3
 
 
 def test_params_struct_layout_matches_header(T):
@@ -86,7 +86,7 @@ def test_design_rejects_bad_arguments(T):
     lib = T.load()
     p = T.default_params()
     n = lib.t41rx_coeff_blob_bytes(512)
-    assert n == 4 * (8 + 28 + 46 + 48 + 32 + 5 + 11 + 16 + 1024)
+    assert n == 4 * (24 + 28 + 46 + 48 + 32 + 5 + 11 + 16 + 1024)  # 24-word header: 8 + t41rx_params padded to 16
     assert lib.t41rx_coeff_blob_bytes(500) == 0
     buf = (C.c_uint8 * n)()
     assert lib.t41rx_design_coeffs(C.byref(p), buf, n - 1) == _lib.ERR_ARG

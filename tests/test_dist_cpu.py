@@ -68,3 +68,41 @@ def test_two_rank_coefficient_broadcast(built):
     assert res[0][1] == want and res[1][1] == want
     assert (res[0][2], res[0][3]) == (0, 2048) and (res[1][2], res[1][3]) == (2048, 4096)
     assert res[0][4] == 2.0 and res[1][4] == 2.0
+
+
+def _run_bench(args, env_extra=None, timeout=240):
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+    return p, lines
+
+
+def test_bench_launcher_starts_its_own_ranks(built):
+    """`python bench.py --gpus 2` with no torch.distributed environment: the parent starts two rank
+    processes itself (the driver's command shape), they rendezvous (gloo in --dry-run), shard the
+    channels with t41_sdr_amd.dist, broadcast rank 0's coefficient blob, and rank 0 prints ONE JSON
+    line with the world size it observed"""
+    p, lines = _run_bench(["--gpus", "2", "--dry-run", "--workload", "ssb"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len(lines) == 1
+    d = lines[0]
+    assert d["dry_run"] is True and d["n_gpus"] == 2 and d["world_size_observed"] == 2
+    assert d["channels"] == [0, 4096] and d["wall_max"] == 2.0
+
+
+def test_bench_refuses_a_world_size_mismatch(built):
+    """--gpus must equal what the process group reports: one rank launched under a 1-rank environment
+    but told --gpus 2 fails instead of printing a line that claims two GPUs"""
+    p, lines = _run_bench(["--gpus", "2", "--dry-run"], env_extra=dict(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert p.returncode != 0 and not lines
+    assert "process group has 1 ranks" in (p.stderr + p.stdout)
+
+
+def test_bench_launcher_propagates_a_failing_rank(built):
+    p, lines = _run_bench(["--gpus", "2", "--dry-run", "--workload", "ssb"], env_extra=dict(T41RX_BENCH_FAIL_RANK="1"))
+    assert p.returncode != 0 and not lines

@@ -156,7 +156,7 @@ def test_parity_agc(T, agcmode, mode, nfr, segs):
     assert np.isfinite(got).all()
     assert err.max() <= (AM_TOL if mode == 2 else TOL), (err.max(), np.unravel_index(err.argmax(), err.shape))
     # the gain-law state itself: `volts` after the last sample (state record: 768 + 200 history floats, word 2)
-    st = rx.get_state().view(np.float32).reshape(nch, -1)
+    st = rx.state_records()
     volts_ref = np.array([ob.tap(c, O.TAP_AGC_VOLTS, 256)[-1] for c in range(nch)])
     # what this case is here for: the state changes its signals drive the gain law through
     edges = sum(ob.tap(c, O.TAP_AGC_EDGES, 25).reshape(5, 5) for c in range(nch))
@@ -453,7 +453,7 @@ def test_agc_edge_inputs(T, agcmode):
     Z = np.zeros((nch, 2 * L), np.float32)
     got, rx = gpu_run(T, kw, nco, Z, Z)
     assert np.array_equal(got, np.zeros_like(got))
-    st = rx.get_state().view(np.float32).reshape(nch, -1)
+    st = rx.state_records()
     assert np.all(st[:, 768 + 200 + 2] == np.float32(O.coeff_arrays(O.design(O.default_params(**kw)), 512)["agc"][9]))  # min_volts
     rng = np.random.default_rng(1)
     I = np.sign(rng.standard_normal((nch, 6 * L))).astype(np.float32) * 0.999
@@ -531,3 +531,179 @@ def test_full_batch_properties(T):
     inband = spec[:, (f > 300) & (f < 2900)].abs().amax(dim=1)
     far = spec[:, f > 20000].abs().amax(dim=1)
     assert float((far / inband).max()) < 1e-3
+
+
+# ---- stage-level attribution: the C ABI's taps against the oracle's, stage by stage ----
+@pytest.mark.parametrize("mode,flo,fhi", [(0, 200, 3000), (1, -3000, -200), (2, -3000, 3000), (3, 200, 3000)],
+                         ids=["usb", "lsb", "am", "nfm"])
+def test_stage_taps_match_the_oracle(T, mode, flo, fhi):
+    """post-NCO, post-decimation and demodulator taps (t41rx_set_debug_taps) vs T41O_TAP_POST_NCO_*,
+    TAP_DEC_*, TAP_DEMOD, frame by frame from reset: the first frame carries the oscillator's
+    start-up transient (Freq_Shift.cpp:128-139), so a regression there shows up at its stage."""
+    import torch
+    nch, nfr, N, D = 6, 3, 512, 256
+    nco = siggen.nco_grid(nch, seed=21)
+    if mode == 3:
+        I, Q = siggen.make_fm(nch, nfr * L, nco, seed=22)
+    else:
+        I, Q = siggen.make_iq(nch, nfr * L, nco, mode=mode, seed=22)
+    kw = dict(mode=mode, FLoCut=flo, FHiCut=fhi)
+    rx = T.RxChain(nch, T.default_params(**kw), NCOFreq=nco)
+    t_nco = torch.zeros(nch, 2 * L, device="cuda")
+    t_dec = torch.zeros(nch, N, device="cuda")
+    t_dem = torch.zeros(nch, D, device="cuda")
+    rx.set_debug_taps(t_nco, t_dec, t_dem)
+    ob = O.OracleBatch(O.default_params(**kw), nco)
+    dI, dQ = torch.from_numpy(I).cuda(), torch.from_numpy(Q).cuda()
+    rel = lambda a, b: float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))  # noqa: E731
+    for f in range(nfr):
+        sl = slice(f * L, (f + 1) * L)
+        out = rx.ProcessIQData(dI[:, sl].contiguous(), dQ[:, sl].contiguous())
+        torch.cuda.synchronize()
+        ref = ob.process(I[:, sl], Q[:, sl])
+        g_nco, g_dec, g_dem = t_nco.cpu().numpy(), t_dec.cpu().numpy(), t_dem.cpu().numpy()
+        for c in range(nch):
+            r_nco = np.concatenate([ob.tap(c, O.TAP_POST_NCO_I, L), ob.tap(c, O.TAP_POST_NCO_Q, L)])
+            r_dec = np.concatenate([ob.tap(c, O.TAP_DEC_I, D), ob.tap(c, O.TAP_DEC_Q, D)])
+            r_dem = ob.tap(c, O.TAP_DEMOD, D)
+            assert rel(g_nco[c], r_nco) <= TOL, ("post_nco", f, c)
+            if mode != 3:  # NFM: the dec tap of the kernel is the discriminator's output (audio, 0), checked as demod below
+                assert rel(g_dec[c], r_dec) <= TOL, ("dec", f, c)
+            assert rel(g_dem[c], r_dem) <= (AM_TOL if mode == 2 else TOL), ("demod", f, c)
+        assert siggen.block_rel_err(out.cpu().numpy(), ref, L).max() <= (AM_TOL if mode == 2 else TOL)
+    # more frames than the tap buffers hold: refused, nothing written out of bounds
+    from t41_sdr_amd import _lib
+    with pytest.raises(T.T41RxError) as e:
+        rx.ProcessIQData(dI[:, :2 * L].contiguous(), dQ[:, :2 * L].contiguous())
+    assert e.value.status == _lib.ERR_ARG
+    rx.set_debug_taps(None, None, None)
+    rx.ProcessIQData(dI[:, :2 * L].contiguous(), dQ[:, :2 * L].contiguous())
+
+
+def test_broadcast_blob_carries_the_parameters(T):
+    """t41rx_set_coeffs (the broadcast path): a context created with other parameters that
+    installs rank 0's blob runs rank 0's configuration -- AGC on into an AGC-off context, and the
+    other way round -- and reports its parameters"""
+    import torch
+    nch = 6
+    nco = siggen.nco_grid(nch, seed=31)
+    I, Q = siggen.make_iq(nch, 5 * L, nco, seed=32, mode=1)
+    I, Q = siggen.fade(I, Q, [(0.5, 1.0), (0.5, 0.15)])
+    dI, dQ = torch.from_numpy(I).cuda(), torch.from_numpy(Q).cuda()
+    for src_kw, dst_kw in ((dict(mode=1, FLoCut=-2800, FHiCut=-250, AGCMode=3, audioVolume=40), dict()),
+                           (dict(mode=1, FLoCut=-2800, FHiCut=-250, AGCMode=0, audioVolume=40), dict(AGCMode=2))):
+        blob = T.design_coeffs(T.default_params(**src_kw))
+        rx = T.RxChain(nch, T.default_params(**dst_kw), NCOFreq=nco)
+        rx.set_coeffs(blob)
+        got = rx.get_params()
+        for k, v in src_kw.items():
+            assert getattr(got, k) == v
+        assert T.blob_params(blob).AGCMode == src_kw["AGCMode"]
+        out = rx.ProcessIQData(dI, dQ).cpu().numpy()
+        ref = oracle_run(src_kw, nco, I, Q)
+        assert siggen.block_rel_err(out, ref, L).max() <= TOL
+        # a later filter change on that context starts from the installed parameters
+        rx.CalcFilters(**{k: getattr(got, k) for k in ("mode", "FLoCut", "FHiCut", "AGCMode", "audioVolume")})
+        assert np.array_equal(rx.coeffs(), blob)
+    # a blob with a damaged parameter section is refused
+    from t41_sdr_amd import _lib
+    bad = T.design_coeffs(T.default_params()).copy()
+    bad[4 * 8 + 4 * 8] = 77  # AGCMode word of the parameter section
+    with pytest.raises(T.T41RxError) as e:
+        T.RxChain(2, T.default_params()).set_coeffs(bad)
+    assert e.value.status == _lib.ERR_STATE
+
+
+def test_iq_amplitude_correction_of_minus_one(T):
+    """IQAmpCorrectionFactor = -1 makes the reference's I <- I * (-A) a multiplication by +1: the
+    specialised kernel that folds the usual sign flip into the RF gain must not be chosen"""
+    nch = 5
+    nco = siggen.nco_grid(nch, seed=41)
+    for mode, flo, fhi in ((0, 200, 3000), (2, -3000, 3000)):
+        kw = dict(mode=mode, FLoCut=flo, FHiCut=fhi, IQAmpCorrectionFactor=-1.0)
+        I, Q = siggen.make_iq(nch, 3 * L, nco, seed=42, mode=mode)
+        got, _ = gpu_run(T, kw, nco, I, Q)
+        assert siggen.block_rel_err(got, oracle_run(kw, nco, I, Q), L).max() <= (AM_TOL if mode == 2 else TOL)
+
+
+def test_checkpoint_header_and_out_buffer_validation(T):
+    import torch
+    from t41_sdr_amd import _lib
+    rx = T.RxChain(4, T.default_params())
+    snap = rx.get_state()
+    assert snap.size == rx.state_records(snap).size * 4 + 32
+    with pytest.raises(T.T41RxError) as e:  # a checkpoint of another batch size / FFT length of the same total size class
+        T.RxChain(3, T.default_params()).set_state(snap)
+    assert e.value.status == _lib.ERR_STATE
+    bad = snap.copy()
+    bad[4] ^= 0xFF  # abi word
+    with pytest.raises(T.T41RxError) as e:
+        rx.set_state(bad)
+    assert e.value.status == _lib.ERR_STATE
+    bad = snap.copy()
+    rec = bad[32:].view(np.float32).reshape(4, -1)
+    rec[1, 768 + 200 + 4] = np.frombuffer(np.int32(9).tobytes(), np.float32)[0]  # AGC state word out of range
+    with pytest.raises(T.T41RxError) as e:
+        rx.set_state(bad)
+    assert e.value.status == _lib.ERR_STATE
+    rx.set_state(snap)
+    x = torch.zeros(4, L, device="cuda")
+    for wrong in (torch.zeros(4, L + 4, device="cuda"), torch.zeros(4, L, device="cuda", dtype=torch.float64),
+                  torch.zeros(L, 4, device="cuda").t(), torch.zeros(4, L)):
+        with pytest.raises(ValueError):
+            rx.ProcessIQData(x, x, out=wrong)
+    h = np.zeros((4, L), np.float32)
+    with pytest.raises(ValueError):
+        rx.ProcessIQData(h, h, out=np.zeros((4, L), np.float64))
+    with pytest.raises(ValueError):
+        rx.ProcessIQData(h, h, out=np.zeros((L, 4), np.float32).T)
+
+
+# ---- BASELINE.json configs 3 and 4 at full size, through properties + an oracle sample ----
+def test_full_batch_nfm(T):
+    """config 3: NFM, 4096 channels: finite, channel-independent (a permutation of the channels
+    permutes the outputs exactly), and a 64-channel sample agrees with the oracle"""
+    import torch
+    nch, nfr = 4096, 2
+    rng = np.random.default_rng(333)
+    nco = (rng.integers(-860, 801, nch) * 50).astype(np.int32)
+    kw = dict(mode=3, FLoCut=200, FHiCut=3000, nfmFilterBW=12000)
+    idx = np.sort(rng.choice(nch, 64, replace=False))
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = 0.2 * torch.randn(nch, nfr * L, generator=g, device="cuda")
+    y = 0.2 * torch.randn(nch, nfr * L, generator=g, device="cuda")
+    fi, fq = siggen.make_fm(64, nfr * L, nco[idx], seed=6)  # real FM carriers on the sampled channels
+    x[torch.from_numpy(idx).cuda()] = torch.from_numpy(fi).cuda()
+    y[torch.from_numpy(idx).cuda()] = torch.from_numpy(fq).cuda()
+    out = T.RxChain(nch, T.default_params(**kw), NCOFreq=nco).ProcessIQData(x, y)
+    assert torch.isfinite(out).all()
+    perm = torch.randperm(nch, generator=torch.Generator().manual_seed(7))
+    outp = T.RxChain(nch, T.default_params(**kw), NCOFreq=nco[perm.numpy()]).ProcessIQData(x[perm.cuda()].contiguous(), y[perm.cuda()].contiguous())
+    assert torch.equal(outp, out[perm.cuda()])
+    ref = oracle_run(kw, nco[idx], fi, fq)
+    assert siggen.block_rel_err(out[torch.from_numpy(idx).cuda()].cpu().numpy(), ref, L).max() <= TOL
+
+
+def test_full_batch_fft4096(T):
+    """config 4: the 4096-point fast convolution at 1024 channels x 16384 samples: finite,
+    channel-independent, frame-split invariant, and a 32-channel sample agrees with the oracle"""
+    import torch
+    nch, nfr, L4 = 1024, 2, 16384
+    rng = np.random.default_rng(444)
+    nco = (rng.integers(-860, 801, nch) * 50).astype(np.int32)
+    kw = dict(fft_length=4096, mode=0, FLoCut=400, FHiCut=600)
+    g = torch.Generator(device="cuda").manual_seed(8)
+    x = 0.2 * torch.randn(nch, nfr * L4, generator=g, device="cuda")
+    y = 0.2 * torch.randn(nch, nfr * L4, generator=g, device="cuda")
+    out = T.RxChain(nch, T.default_params(**kw), NCOFreq=nco).ProcessIQData(x, y)
+    assert torch.isfinite(out).all()
+    rx2 = T.RxChain(nch, T.default_params(**kw), NCOFreq=nco)
+    parts = [rx2.ProcessIQData(x[:, k * L4:(k + 1) * L4].contiguous(), y[:, k * L4:(k + 1) * L4].contiguous()) for k in range(nfr)]
+    assert torch.equal(torch.cat(parts, dim=1), out)
+    perm = torch.randperm(nch, generator=torch.Generator().manual_seed(9))
+    outp = T.RxChain(nch, T.default_params(**kw), NCOFreq=nco[perm.numpy()]).ProcessIQData(x[perm.cuda()].contiguous(), y[perm.cuda()].contiguous())
+    assert torch.equal(outp, out[perm.cuda()])
+    idx = np.sort(rng.choice(nch, 32, replace=False))
+    sel = torch.from_numpy(idx).cuda()
+    ref = oracle_run(kw, nco[idx], x[sel].cpu().numpy(), y[sel].cpu().numpy())
+    assert siggen.block_rel_err(out[sel].cpu().numpy(), ref, L4).max() <= TOL

@@ -10,6 +10,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -37,6 +38,7 @@ struct t41rx_ctx {
   float2 *d_tab4k = nullptr;
   float *d_mid = nullptr, *d_aud24 = nullptr;
   int scratch_frames = 0;
+  int nco_sel = 0;               // long FFT: which NcoState copy is current (flips with every process call)
   // staging for t41rx_process_host
   float *d_in_i = nullptr, *d_in_q = nullptr, *d_out = nullptr;
   size_t staging_floats = 0;
@@ -208,8 +210,10 @@ int reset_state(t41rx_ctx *ctx) {
     ns.phase = 0;  // Osc_Vect_Q = 1, Osc_Vect_I = 0 (Freq_Shift.cpp:13-14)
     ns.r = 1.0;
     std::memcpy(h.data() + sf * (size_t)c + kStNco, &ns, sizeof(ns));
+    std::memcpy(h.data() + sf * (size_t)c + kStNco + 4, &ns, sizeof(ns));
   }
   HIP_TRY(hipMemcpy(ctx->d_state, h.data(), sizeof(float) * h.size(), hipMemcpyHostToDevice));
+  ctx->nco_sel = 0;
   return T41RX_OK;
 }
 
@@ -489,6 +493,16 @@ int process_device_impl(t41rx_ctx *ctx, const float *dI, const float *dQ, float 
     a.plain = ((iq_on ? gi == -1.0f : gi == 1.0f) && sc[kScBandGain] == 1.0f && (!iq_on || sc[kScIqPhase] == 0.0f)) ? 1 : 0;
   }
   a.q15 = q15 ? 1 : 0;
+  a.nco_rd = ctx->nco_sel;
+  {
+    // Segment-parallel kernels of the long-FFT pipeline: about 4096 wave slots (256 CUs x 16) to
+    // fill; a wave that starts inside the call pays one extra sub-block to rebuild its filter
+    // memories, so runs are as long as still gives every slot a wave (and never longer than 8).
+    const long segs = (long)a.nframes, waves = 4096;
+    long run = (long)ctx->nchan * segs / waves;
+    if (const char *e = std::getenv("T41RX_SEG_RUN")) run = std::atol(e);  // experiments
+    a.seg_run = (int)(run < 1 ? 1 : (run > 8 ? 8 : (run > segs ? segs : run)));
+  }
   a.agc = ctx->params.AGCMode != 0 ? 1 : 0;
   if (a.agc && (int)blob_view(ctx->blob.data()).agc[kAgcAttackBuffsize] != kAgcDelay)
     return fail(T41RX_ERR_STATE, "coefficient blob carries an AGC look-ahead the kernel is not built for");
@@ -503,6 +517,7 @@ int process_device_impl(t41rx_ctx *ctx, const float *dI, const float *dQ, float 
   a.spect_max = ctx->spect_max;
   hipError_t e = launch_rx(a, ctx->params.fft_length, ctx->params.mode, (hipStream_t)hip_stream);
   if (e != hipSuccess) return hip_fail(e, "kernel launch");
+  if (seg > 1) ctx->nco_sel ^= 1;  // the kernels wrote the other copy
   return T41RX_OK;
 }
 
@@ -580,6 +595,13 @@ int t41rx_get_state(t41rx_ctx *ctx, void *host_buf, size_t bytes) {
   std::memcpy(host_buf, hdr, sizeof(hdr));
   HIP_TRY(hipMemcpy(static_cast<char *>(host_buf) + kStateHeaderBytes, ctx->d_state,
                     t41rx_state_bytes(ctx) - kStateHeaderBytes, hipMemcpyDeviceToHost));
+  // canonical checkpoint: the current oscillator state in both slots
+  float *rec = reinterpret_cast<float *>(static_cast<char *>(host_buf) + kStateHeaderBytes);
+  const size_t sf = state_floats(ctx->params.fft_length);
+  for (int c = 0; c < ctx->nchan; ++c) {
+    float *n = rec + sf * (size_t)c + kStNco;
+    std::memcpy(n + 4 * (ctx->nco_sel ^ 1), n + 4 * ctx->nco_sel, sizeof(NcoState));
+  }
   return T41RX_OK;
 }
 
@@ -610,6 +632,7 @@ int t41rx_set_state(t41rx_ctx *ctx, const void *host_buf, size_t bytes) {
   DeviceGuard g(ctx->device);
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(ctx->d_state, rec, bytes - kStateHeaderBytes, hipMemcpyHostToDevice));
+  ctx->nco_sel = 0;  // (a checkpoint carries the current oscillator state in both slots)
   return T41RX_OK;
 }
 

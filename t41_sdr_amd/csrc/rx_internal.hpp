@@ -104,7 +104,8 @@ constexpr int kMiscNfmI = 4;    // nfmdemod last_sample_i/q, Demod.cpp:221-222
 constexpr int kMiscNfmQ = 5;
 constexpr int kMiscLp1 = 8;     // biquad_lowpass1_state[4]
 constexpr int kMiscMaxSqAve = 12; // audioMaxSquaredAve, Process.cpp:570
-constexpr int kStNco = 200;     // 8 floats = uint64 phase (turns, 0.64) + double |V|^2... see NcoState
+constexpr int kStNco = 200;     // 8 floats = two NcoState (16 B each); FFT_LENGTH 512 uses the first, the long
+                                // FFT lengths alternate between them from call to call (rx_kernels.hip)
 constexpr int kStOverlap = 256; // fft_length floats: last_sample_buffer_L/R as [k][lane] (re,im)
 struct NcoState {
   uint64_t phase;  // arg(Osc_Vect_Q + j Osc_Vect_I) in turns, 0.64 fixed point

@@ -971,8 +971,21 @@ static_assert(Geo<1>::kTotal * sizeof(float) == 40960, "PART 1/2: four workgroup
 static_assert(!Geo<0>::kResident || (Geo<0>::kH1 + 24 <= Geo<0>::kSlice && Geo<0>::kScr + 8 * kFftRow * 2 <= Geo<0>::kXF &&
                                      Geo<0>::kI1 + 284 <= Geo<0>::kXF && Geo<0>::kScr >= 68), "resident LDS layout");
 
-template <int MODE, bool DEBUG, int PART, bool PLAIN, bool AGC = false, bool WQ15 = false>
+// SEGPAR (PART 1 without NFM, PART 2 without AGC / AM): one wave per (channel, run of a.seg_run
+// consecutive 2048-sample segments) instead of one wave per channel looping over all its segments
+// -- the host picks the run length so that the long-FFT pipeline, whose 1024-channel batch
+// otherwise leaves 12 of a CU's 16 wave slots empty, fills the chip once or twice over.
+// A wave that does not start at the first segment of the call rebuilds the filter memories it
+// needs from the PRECEDING input instead of receiving them from its predecessor: front end = one
+// extra sub-block (the previous segment's last 512 samples) through DC high-pass, mixer and /4
+// decimator, which yields the /4 history, the last 48 /4 outputs (= the /2 history) and both DC
+// high-pass chain states exactly (a1^512 ~ 1e-35, the oscillator phase is closed form and past its
+// start-up transient); back end = the previous segment's last 28 audio samples.  The channel's
+// state is written by the wave that READ it (the one that starts the call), from the call's last
+// samples in the same way: a wave of a later run may execute before that one has started.
+template <int MODE, bool DEBUG, int PART, bool PLAIN, bool AGC = false, bool WQ15 = false, bool SEGPAR = false>
 __global__ __launch_bounds__(Geo<PART>::kWaves * 64, 4) void rx512_kernel(const RxArgs a) {
+  static_assert(!SEGPAR || (PART == 1 && MODE != kModeNfm) || (PART == 2 && MODE == kModeSsb && !AGC), "SEGPAR variants");
   typedef Geo<PART> G;
   constexpr bool KEEP = G::kResident;  // streaming state stays on chip across the frames of a launch
   constexpr int NW = G::kWaves;
@@ -987,7 +1000,11 @@ __global__ __launch_bounds__(Geo<PART>::kWaves * 64, 4) void rx512_kernel(const 
   // being hoisted out of the frame loop, kept live through every other phase and spilled.
   int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int ch = blockIdx.x * NW + wv;
+  const int job = blockIdx.x * NW + wv;                       // SEGPAR: (channel, run) pairs, run fastest
+  const int runs = SEGPAR ? (a.nframes + a.seg_run - 1) / a.seg_run : 1;
+  const int ch = SEGPAR ? job / runs : job;
+  const int seg0 = SEGPAR ? (job - ch * runs) * a.seg_run : 0;                                      // first segment / frame this wave runs
+  const int seg1 = SEGPAR ? (seg0 + a.seg_run < a.nframes ? seg0 + a.seg_run : a.nframes) : a.nframes;  // one past the last
 
   // mask + twiddles are staged in LDS once per workgroup (the only workgroup barrier).  The
   // staging runs AFTER the first frame's global loads have been issued, so its latency and the
@@ -1017,7 +1034,7 @@ __global__ __launch_bounds__(Geo<PART>::kWaves * 64, 4) void rx512_kernel(const 
   // per-lane constants of the DC high-pass scan
   const float2 hp8 = a.tab[kTabHp8 + lane];
   const float2 hp4 = a.tab[kTabHp4 + lane];
-  if (ch >= a.nchan) {  // ragged last workgroup: help with the staging, meet the barrier, leave
+  if (ch >= a.nchan) {  // ragged last workgroup: help with the staging, meet the barrier, leave (SEGPAR: ch = job / segments)
     if (PART != 2) stage_tables();
     return;
   }
@@ -1035,11 +1052,16 @@ __global__ __launch_bounds__(Geo<PART>::kWaves * 64, 4) void rx512_kernel(const 
   // per-channel NCO constants and state (wave-uniform).  Only the LOADS are issued here; the
   // values are made uniform (which waits for them) after the first frame's input loads are in
   // flight, so the kernel's cold start is one memory round trip, not a chain of them.
-  NcoState *ncs = reinterpret_cast<NcoState *>(st + kStNco);
+  // Long FFT: the oscillator state is kept twice and the copies alternate from call to call
+  // (a.nco_rd = the one to read; the other one is written).  With one wave per segment every wave
+  // of a channel needs the phase the call STARTED with, and a wave may start -- on another XCD --
+  // after the wave that ends the call has already stored the new one.
+  const NcoState *ncs_rd = reinterpret_cast<const NcoState *>(st + kStNco) + (PART == 0 ? 0 : a.nco_rd);
+  NcoState *ncs = reinterpret_cast<NcoState *>(st + kStNco) + (PART == 0 ? 0 : (a.nco_rd ^ 1));
   const uint64_t raw_dphi = nco->phase_inc;
   const double raw_rs = nco->r_star_sq;
-  const uint64_t raw_phase = ncs->phase;
-  const double raw_r = ncs->r;
+  const uint64_t raw_phase = ncs_rd->phase;
+  const double raw_r = ncs_rd->r;
   const float raw_dc = st[kStMisc + kMiscDc];
   uint64_t dphi = 0, phase0 = 0;
   double osc_r = 1.0;
@@ -1071,9 +1093,42 @@ __global__ __launch_bounds__(Geo<PART>::kWaves * 64, 4) void rx512_kernel(const 
     if (lane == 28) stamp_acc = rt;
   }
 #endif
-  for (int f = 0; f < a.nframes; ++f) {
+  // SEGPAR back end: the x2 interpolator's outputs for the four audio samples that END at `end`
+  // (what the wave owning them computes for its inputs 252..255 from the window end[-28 .. -1];
+  // every lane computes all eight: uniform addresses).  xp[1..7] = the x4 interpolator's history.
+  auto x2_tail = [&](const float *end, float (&xp)[8]) {
+    float wp[28];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const float4 t = *reinterpret_cast<const float4 *>(end - 28 + 4 * i);
+      wp[4 * i] = t.x;
+      wp[4 * i + 1] = t.y;
+      wp[4 * i + 2] = t.z;
+      wp[4 * i + 3] = t.w;
+    }
+    f2 up[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) up[u] = splat(0.0f);
+#pragma unroll
+    for (int b = 0; b < 24; b += 8) {
+      float ci[16];
+      load_taps<16>(ci, (CFloatPtr)cf0->int1 + 2 * b);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) up[u] = pk_fma(splat(wp[u + b + t + 1]), f2{ci[1 + 2 * t], ci[2 * t]}, up[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      xp[2 * u] = up[u].x;
+      xp[2 * u + 1] = up[u].y;
+    }
+  };
+  for (int f = seg0; f < seg1; ++f) {
     PRIO(3);
     FRESH_LANE();
+    const bool first_iter = (f == seg0);
     const size_t fbase = ((size_t)(T41RX_ABLATE == 9 ? (ch & 15) : ch) * a.nframes + f) * L;
     // (WQ15: two samples per float slot, so sample offsets halve)
     const float *__restrict__ gI = a.I + (WQ15 ? fbase / 2 : fbase);
@@ -1100,7 +1155,19 @@ __global__ __launch_bounds__(Geo<PART>::kWaves * 64, 4) void rx512_kernel(const 
       // back half of the 4096 pipeline: this segment's 256 audio samples come from the
       // fast-convolution kernel
       const float *au = a.aud24 + ((size_t)ch * a.nframes + f) * D;
-      if (f == 0) {
+      if (SEGPAR && first_iter && f > 0) {
+        // this wave starts inside the call: both interpolator histories come from the previous
+        // segment's audio -- the x2 history is its last 23 samples as they are, the x4 history the
+        // last 7 outputs of the x2 interpolator (x2_tail)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) aud[j] = au[lane + 64 * j];
+        if (lane < 6) hist1 = *reinterpret_cast<const float4 *>(au - 24 + 4 * lane);
+        float xp[8];
+        x2_tail(au, xp);
+        hist2 = xp[1];  // lane i = entry i (i = 1..7)
+#pragma unroll
+        for (int i = 2; i < 8; ++i) hist2 = (lane == i) ? xp[i] : hist2;
+      } else if (first_iter) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) aud[j] = au[lane + 64 * j];
         if (lane < 6) hist1 = *reinterpret_cast<const float4 *>(st + kStInt1 + 4 * lane);
@@ -1111,7 +1178,7 @@ __global__ __launch_bounds__(Geo<PART>::kWaves * 64, 4) void rx512_kernel(const 
         hist1 = hist1c;
         hist2 = hist2c;
       }
-      if (f + 1 < a.nframes) {
+      if (f + 1 < seg1) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) audn[j] = au[D + lane + 64 * j];
       }
@@ -1125,9 +1192,21 @@ __global__ __launch_bounds__(Geo<PART>::kWaves * 64, 4) void rx512_kernel(const 
       // KEEP: the same for the inputs -- the next frame's first two sub-blocks and its I tail are
       // requested while the current frame's last two sub-blocks are processed and arrive under its
       // back end, so a wave does not sit out a memory round trip at every frame start.
-      const bool hist_carried = (PART == 1 || KEEP) && f > 0;
-      const bool carried = (PART == 1 || (KEEP && T41RX_PF >= 1)) && f > 0;   // sub-block 0 (and the tail)
-      const bool carried1 = (PART == 1 || (KEEP && T41RX_PF >= 2)) && f > 0;  // sub-block 1
+      const bool hist_carried = (PART == 1 || KEEP) && !first_iter;
+      const bool carried = (PART == 1 || (KEEP && T41RX_PF >= 1)) && !first_iter;   // sub-block 0 (and the tail)
+      const bool carried1 = (PART == 1 || (KEEP && T41RX_PF >= 2)) && !first_iter;  // sub-block 1
+      const bool preroll = SEGPAR && first_iter && f > 0;  // this wave rebuilds its filter memories from the preceding input
+      if (preroll) {  // requested first, into register set 1 (sub-block 1 is requested once the pre-roll is done)
+        if (!WQ15) {
+          pI0[1] = ldg_stream(gI - 512 + 8 * lane);
+          pI1[1] = ldg_stream(gI - 512 + 8 * lane + 4);
+          pQ0[1] = ldg_stream(gQ - 512 + 8 * lane);
+          pQ1[1] = ldg_stream(gQ - 512 + 8 * lane + 4);
+        } else {
+          pI0[1] = ldg_stream(gI - 256 + 4 * lane);
+          pQ0[1] = ldg_stream(gQ - 256 + 4 * lane);
+        }
+      }
       float4 tailI;
       if (KEEP && carried) {
         tailI = WQ15 ? make_float4(q15_lo(tailNq.x), q15_hi(tailNq.x), q15_lo(tailNq.y), q15_hi(tailNq.y)) : tailN;
@@ -1149,7 +1228,7 @@ __global__ __launch_bounds__(Geo<PART>::kWaves * 64, 4) void rx512_kernel(const 
       }
       float4 h1 = make_float4(0, 0, 0, 0), h2 = make_float4(0, 0, 0, 0);
       float4 ovl0 = make_float4(0, 0, 0, 0), ovl1 = ovl0, ovl2 = ovl0;  // KEEP, first frame: overlap block, x2 history
-      if (!hist_carried) {
+      if (!hist_carried && !preroll) {
         if (lane < 14) h1 = *reinterpret_cast<const float4 *>(st + kStDec1 + 4 * lane);
         if (lane < 24) h2 = *reinterpret_cast<const float4 *>(st + kStDec2 + 4 * lane);
         if (KEEP) {  // the rest of the channel's record: overlap block, interpolator histories
@@ -1178,9 +1257,11 @@ __global__ __launch_bounds__(Geo<PART>::kWaves * 64, 4) void rx512_kernel(const 
         }
       }
       STAMP(16);  // prologue a: issue + scalar (SMEM) gains
-      if (f == 0) stage_tables();
+      if (first_iter) stage_tables();
       STAMP(17);  // prologue b: table staging + workgroup barrier (first vmcnt wait)
-      if (!WQ15) {
+      if (preroll) {
+        // (register set 1 still holds the pre-roll)
+      } else if (!WQ15) {
         if (!carried1) {
           pI0[1] = ldg_stream(gI + 512 + 8 * lane);
           pI1[1] = ldg_stream(gI + 512 + 8 * lane + 4);
@@ -1195,7 +1276,7 @@ __global__ __launch_bounds__(Geo<PART>::kWaves * 64, 4) void rx512_kernel(const 
       // ---- delay lines -> LDS (first frame of a launch / every segment-0; afterwards they are
       // where the history rolls left them)
       wave_sync();
-      if (!hist_carried) {
+      if (!hist_carried && !preroll) {
         if (lane < 14) *reinterpret_cast<float4 *>(lds + kX + 2 * xpad(2 * lane)) = h1;
         if (lane < 24) *reinterpret_cast<float4 *>(lds + kY1 + y1slot(lane)) = h2;
         if (KEEP) {
@@ -1205,12 +1286,95 @@ __global__ __launch_bounds__(Geo<PART>::kWaves * 64, 4) void rx512_kernel(const 
         }
       }
       STAMP(18);  // prologue c: delay lines -> LDS
-      if (f == 0) {
+      if (first_iter) {
         dphi = uniform_u64(raw_dphi);
-        phase0 = uniform_u64(raw_phase);
+        phase0 = uniform_u64(raw_phase) + (uint64_t)f * (uint64_t)L * dphi;  // (f = 0 unless SEGPAR: closed form)
         osc_r = uniform_f64(raw_r);
         dc_carry = uniform_f32(raw_dc);
-        transient = fabs(osc_r * osc_r - uniform_f64(raw_rs)) > 1e-13;
+        // the amplitude loop's start-up lasts ~300 samples after a reset: over before segment 1
+        transient = !preroll && fabs(osc_r * osc_r - uniform_f64(raw_rs)) > 1e-13;
+      }
+      // SEGPAR: filter memories rebuilt from 512 input samples (already in registers) that END where
+      // the oscillator phase is phase_end: the /4 history goes to X, the last 48 /4 outputs to the
+      // /2 history slots of Y1; returns the states of the two DC high-pass chains after them.
+      auto rebuild_from = [&](float4 rI0, float4 rI1, float4 rQ0, float4 rQ1, uint64_t phase_end) -> f2 {
+        cf z[8];
+        if (!WQ15) {
+          z[0] = cf{rI0.x * g_rf_i, rQ0.x * g_rf};
+          z[1] = cf{rI0.y * g_rf_i, rQ0.y * g_rf};
+          z[2] = cf{rI0.z * g_rf_i, rQ0.z * g_rf};
+          z[3] = cf{rI0.w * g_rf_i, rQ0.w * g_rf};
+          z[4] = cf{rI1.x * g_rf_i, rQ1.x * g_rf};
+          z[5] = cf{rI1.y * g_rf_i, rQ1.y * g_rf};
+          z[6] = cf{rI1.z * g_rf_i, rQ1.z * g_rf};
+          z[7] = cf{rI1.w * g_rf_i, rQ1.w * g_rf};
+        } else {
+          const float wi[4] = {rI0.x, rI0.y, rI0.z, rI0.w}, wq[4] = {rQ0.x, rQ0.y, rQ0.z, rQ0.w};
+  #pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            z[2 * k] = cf{q15_lo(wi[k]) * g_rf_i, q15_lo(wq[k]) * g_rf};
+            z[2 * k + 1] = cf{q15_hi(wi[k]) * g_rf_i, q15_hi(wq[k]) * g_rf};
+          }
+        }
+        f2 dcs = splat(0.0f);
+        dc_highpass<8>(z, dcs, lane, hp8.x, hp8.y);  // from rest: 512 samples on, its memory of the start is a1^512
+        if (!PLAIN) {
+  #pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            z[k] *= g_iq;
+            z[k].y = fmaf(iq_phase_neg, z[k].x, z[k].y);
+            z[k].x = fmaf(iq_phase_pos, z[k].y, z[k].x);
+          }
+        }
+        {
+          const uint64_t P = phase_end - (uint64_t)(511 - 8 * lane) * dphi;  // sample -512 + 8 lane, + 1
+          const float2 t = reinterpret_cast<const float2 *>(smem)[(int)(P >> 56)];  // (PART 1: the table is in LDS)
+          const uint32_t u = (uint32_t)(P >> 24);
+          const float ang = (float)u * (float)(6.283185307179586476925 / 256.0 / 4294967296.0);
+          const float a2 = ang * ang;
+          const float sn = ang * fmaf(a2, -1.0f / 6.0f, 1.0f);
+          const float cs = fmaf(a2, fmaf(a2, 1.0f / 24.0f, -0.5f), 1.0f);
+          const cf base = cmul(cf{t.x, t.y}, cf{cs, sn});
+  #pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const cf osc = cmul_s(base, cf{nco->wk[k][0], nco->wk[k][1]});
+            z[k] = cmulc(z[k], osc);
+          }
+        }
+        wave_sync();
+        float *xw = lds + kX + 20 * lane;
+  #pragma unroll
+        for (int i = 0; i < 4; ++i)
+          *reinterpret_cast<float4 *>(xw + 2 * (xpad(28 + 2 * i))) = make_float4(z[2 * i].x, z[2 * i].y, z[2 * i + 1].x, z[2 * i + 1].y);
+        wave_sync();
+        cf o1[2];
+        auto pidx = [](int o) { return xpad(o); };
+        fir_pair<kDec1Taps, 1, 5, 18, 6>(xw, pidx, (CFloatPtr)cf0->dec1, o1[0], o1[1]);
+        // its first outputs saw no history and are dropped; the last 48 (lanes 40..63) are the /2 history
+        float4 hh = make_float4(0, 0, 0, 0);
+        if (lane < 14) hh = lds4(lds + kX + 2 * xpad(512 + 2 * lane));
+        wave_sync();
+        if (lane < 14) *reinterpret_cast<float4 *>(lds + kX + 2 * xpad(2 * lane)) = hh;
+        if (lane >= 40) *reinterpret_cast<float4 *>(lds + kY1 + y1slot(lane - 40)) = make_float4(o1[0].x, o1[0].y, o1[1].x, o1[1].y);
+        wave_sync();
+        return dcs;
+      };
+      f2 dc_pre = splat(0.0f);  // SEGPAR: states of the two DC high-pass chains at the end of the preceding segment
+      if (preroll) {
+        const float4 rI0 = pI0[1], rI1 = WQ15 ? pI0[1] : pI1[1], rQ0 = pQ0[1], rQ1 = WQ15 ? pQ0[1] : pQ1[1];
+        // now that set 1 is consumed: this segment's sub-block 1
+        if (!WQ15) {
+          pI0[1] = ldg_stream(gI + 512 + 8 * lane);
+          pI1[1] = ldg_stream(gI + 512 + 8 * lane + 4);
+          pQ0[1] = ldg_stream(gQ + 512 + 8 * lane);
+          pQ1[1] = ldg_stream(gQ + 512 + 8 * lane + 4);
+        } else {
+          pI0[1] = ldg_stream(gI + 256 + 4 * lane);
+          pQ0[1] = ldg_stream(gQ + 256 + 4 * lane);
+        }
+        dc_pre = rebuild_from(rI0, rI1, rQ0, rQ1, phase0);
+        // a frame's first segment: the shared biquad comes from the previous frame's Q (Process.cpp:127-128)
+        if ((f & (seg - 1)) == 0) dc_carry = uniform_f32(dc_pre.y);
       }
 
       // ---- Q's DC-block start state = state after ALL of this frame's I (one shared biquad
@@ -1232,6 +1396,8 @@ __global__ __launch_bounds__(Geo<PART>::kWaves * 64, 4) void rx512_kernel(const 
         }
         const float x[4] = {tailF.x * g_rf, tailF.y * g_rf, tailF.z * g_rf, tailF.w * g_rf};
         dc2 = f2{(g_rf_i != g_rf) ? -dc_carry : dc_carry, dc_highpass_end_state<4>(x, hp4.x, hp4.y)};
+      } else if (preroll) {
+        dc2 = dc_pre;  // inside a frame both chains simply run on
       }
 
       STAMP(15);  // prologue d: NCO/DC state uniformisation + Q's DC-block start state
@@ -1284,7 +1450,7 @@ __global__ __launch_bounds__(Geo<PART>::kWaves * 64, 4) void rx512_kernel(const 
               pQ0[h] = ldg_stream(gQ + o);
             }
           } else if (PART == 1 || (KEEP && T41RX_PF >= 1)) {  // the next segment's / frame's sub-blocks 0 and 1 (same channel: contiguous)
-            if (f + 1 < a.nframes) {
+            if (f + 1 < seg1) {
               if (KEEP && s == 3) {  // and the I tail that decides the next frame's Q start state
                 if (!WQ15) {
                   tailN = *reinterpret_cast<const float4 *>(gI + L + (L - 256) + 4 * lane);
@@ -1448,7 +1614,27 @@ __global__ __launch_bounds__(Geo<PART>::kWaves * 64, 4) void rx512_kernel(const 
       // Issue the small back-end loads now so the FFT hides their latency: interpolator histories,
       // the AGC record; KEEP: the filter mask of this lane (8 x 8 B from the L2-resident table).
       wave_sync();
-      if (!KEEP) {
+      if (SEGPAR && seg0 == 0 && f == seg1 - 1 && seg1 < a.nframes) {
+        // The channel's state is written by the wave that READ it -- the one of the call's first
+        // segment -- and by no other: a wave of a later segment may run (on another XCD) before
+        // this one has started.  What the state must hold is what the call's LAST samples leave
+        // behind, so this wave rebuilds it from them exactly as the others rebuild theirs.
+        const size_t last = (size_t)(a.nframes - 1 - f) * L;  // the call's last segment, relative to this one
+        float4 rI0, rI1, rQ0, rQ1;
+        if (!WQ15) {
+          rI0 = ldg_stream(gI + last + 1536 + 8 * lane);
+          rI1 = ldg_stream(gI + last + 1536 + 8 * lane + 4);
+          rQ0 = ldg_stream(gQ + last + 1536 + 8 * lane);
+          rQ1 = ldg_stream(gQ + last + 1536 + 8 * lane + 4);
+        } else {
+          rI0 = rI1 = ldg_stream(gI + last / 2 + 768 + 4 * lane);
+          rQ0 = rQ1 = ldg_stream(gQ + last / 2 + 768 + 4 * lane);
+        }
+        phase0 += (uint64_t)(a.nframes - 1 - f) * (uint64_t)L * dphi;  // the oscillator phase after the call
+        const f2 dc_end = rebuild_from(rI0, rI1, rQ0, rQ1, phase0);
+        dc_carry = uniform_f32(dc_end.y);
+      }
+      if (!KEEP && (!SEGPAR || (seg0 == 0 && f == seg1 - 1))) {
         if (lane < 14) *reinterpret_cast<float4 *>(st + kStDec1 + 4 * lane) = lds4(lds + kX + 2 * xpad(2 * lane));
         if (lane < 24) *reinterpret_cast<float4 *>(st + kStDec2 + 4 * lane) = lds4(lds + kY1 + y1slot(lane));
         if (PART != 1) {
@@ -1823,7 +2009,7 @@ __global__ __launch_bounds__(Geo<PART>::kWaves * 64, 4) void rx512_kernel(const 
         if (lane < 6) *reinterpret_cast<float4 *>(lds + G::kH1 + 4 * lane) = lds4(lds + kI1 + 256 + 4 * lane);
       } else if (lane < 6) {
         hist1c = lds4(lds + kI1 + 256 + 4 * lane);
-        *reinterpret_cast<float4 *>(st + kStInt1 + 4 * lane) = hist1c;
+        if (!SEGPAR || (seg0 == 0 && seg1 == a.nframes)) *reinterpret_cast<float4 *>(st + kStInt1 + 4 * lane) = hist1c;
       }
       // arm_fir_interpolate_f32: out[2n + j - 1] = sum_t state[n + t] * c[(2 - j) + 2 t]:
       // (out[2n], out[2n+1]) += state[n+t] * (c[2t+1], c[2t])  -- one packed FMA per tap
@@ -1858,9 +2044,21 @@ __global__ __launch_bounds__(Geo<PART>::kWaves * 64, 4) void rx512_kernel(const 
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) w[7 + i] = x1[i];
-      if (!KEEP && lane == 63) {
+      if (!KEEP && lane == 63 && (!SEGPAR || (seg0 == 0 && seg1 == a.nframes))) {
         *reinterpret_cast<float4 *>(st + kStInt2) = make_float4(0.0f, x1[1], x1[2], x1[3]);
         *reinterpret_cast<float4 *>(st + kStInt2 + 4) = make_float4(x1[4], x1[5], x1[6], x1[7]);
+      }
+      if (PART == 2 && SEGPAR && seg0 == 0 && f == seg1 - 1 && seg1 < a.nframes) {
+        // the state is written by the wave that read it (see the front end): what the call's last
+        // audio samples leave behind
+        const float *end = a.aud24 + ((size_t)ch * a.nframes + a.nframes) * D;
+        if (lane < 6) *reinterpret_cast<float4 *>(st + kStInt1 + 4 * lane) = *reinterpret_cast<const float4 *>(end - 24 + 4 * lane);
+        float xp[8];
+        x2_tail(end, xp);
+        if (lane == 0) {
+          *reinterpret_cast<float4 *>(st + kStInt2) = make_float4(0.0f, xp[1], xp[2], xp[3]);
+          *reinterpret_cast<float4 *>(st + kStInt2 + 4) = make_float4(xp[4], xp[5], xp[6], xp[7]);
+        }
       }
       if (PART == 2 || KEEP) {  // the same seven values, kept for the next segment / frame: lane i = entry i
 #pragma unroll
@@ -1983,9 +2181,15 @@ __global__ __launch_bounds__(Geo<PART>::kWaves * 64, 4) void rx512_kernel(const 
     if (lane < 8) st[kStInt2 + lane] = (lane == 0) ? 0.0f : hist2c;
   }
   if (PART != 2 && lane == 0) {
-    ncs->phase = phase0;
-    ncs->r = osc_r;
-    st[kStMisc + kMiscDc] = dc_carry;
+    if (!SEGPAR) {
+      ncs->phase = phase0;
+      ncs->r = osc_r;
+      st[kStMisc + kMiscDc] = dc_carry;
+    } else if (seg0 == 0) {  // (phase0 / dc_carry: advanced to the end of the call above)
+      ncs->phase = phase0;
+      ncs->r = osc_r;
+      st[kStMisc + kMiscDc] = dc_carry;
+    }
   }
 }
 
@@ -2055,9 +2259,11 @@ __global__ __launch_bounds__(256) void fastconv_kernel(const RxArgs a) {
   }
 
   for (int f = 0; f < a.nframes4k; ++f) {
-    // ---- overlap-save assemble (Process.cpp:498-522): [previous N/2 | new N/2]
-    const float4 *prev = reinterpret_cast<const float4 *>(st + kStOverlap);
+    // ---- overlap-save assemble (Process.cpp:498-522): [previous N/2 | new N/2].  Inside a call the
+    // previous block is the preceding frame's `mid` (just read, L2-warm); the state record supplies
+    // it for the call's first frame and receives the last frame's block.
     const float4 *mid = reinterpret_cast<const float4 *>(a.mid + ((size_t)ch * a.nframes4k + f) * (2 * D));
+    const float4 *prev = (f == 0) ? reinterpret_cast<const float4 *>(st + kStOverlap) : mid - N / 4;
     float4 *A4 = reinterpret_cast<float4 *>(smem);
     __syncthreads();  // the previous frame's pass 3 is done with the array
 #pragma unroll
@@ -2068,7 +2274,7 @@ __global__ __launch_bounds__(256) void fastconv_kernel(const RxArgs a) {
       const int rp = e >> 8, rn = (e + N / 4) >> 8;
       A4[rp * (kFcRow / 2) + (e & 255)] = p;
       A4[rn * (kFcRow / 2) + ((e + N / 4) & 255)] = n;
-      reinterpret_cast<float4 *>(st + kStOverlap)[64 * i + lane] = n;  // next frame's "previous"
+      if (f == a.nframes4k - 1) reinterpret_cast<float4 *>(st + kStOverlap)[64 * i + lane] = n;  // next call's "previous"
     }
     __syncthreads();
     // ---- pass 1
@@ -2165,15 +2371,19 @@ static hipError_t launch512(const RxArgs &a, hipStream_t s, bool debug) {
 // FFT_LENGTH 512 R (R = 2, 4, 8): front half (R segments per frame) -> N-point fast convolution -> back half
 static hipError_t launch_long(const RxArgs &a, int mode, hipStream_t s) {
   const int grid = (a.nchan + 3) / 4;
-  if (mode == T41RX_DEMOD_NFM) {
+  // one wave per (channel, segment) wherever the segments can run independently (SEGPAR)
+  const int grid_par = (int)(((size_t)a.nchan * (size_t)((a.nframes + a.seg_run - 1) / a.seg_run) + 3) / 4);
+  if (mode == T41RX_DEMOD_NFM) {  // nfmdemod()'s "last sample" chains the frames: sequential
     if (a.q15)
       hipLaunchKernelGGL((rx512_kernel<kModeNfm, false, 1, false, false, true>), dim3(grid), dim3(256), 0, s, a);
     else
       hipLaunchKernelGGL((rx512_kernel<kModeNfm, false, 1, false>), dim3(grid), dim3(256), 0, s, a);
   } else if (a.q15) {
-    hipLaunchKernelGGL((rx512_kernel<kModeSsb, false, 1, false, false, true>), dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((rx512_kernel<kModeSsb, false, 1, false, false, true, true>), dim3(grid_par), dim3(256), 0, s, a);
+  } else if (a.plain) {  // unit band / IQ gains (the firmware defaults): the correction stage drops out
+    hipLaunchKernelGGL((rx512_kernel<kModeSsb, false, 1, true, false, false, true>), dim3(grid_par), dim3(256), 0, s, a);
   } else {
-    hipLaunchKernelGGL((rx512_kernel<kModeSsb, false, 1, false>), dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((rx512_kernel<kModeSsb, false, 1, false, false, false, true>), dim3(grid_par), dim3(256), 0, s, a);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
@@ -2201,6 +2411,13 @@ static hipError_t launch_long(const RxArgs &a, int mode, hipStream_t s) {
     else                                                                                                          \
       hipLaunchKernelGGL((rx512_kernel<MODEv, false, 2, false, AGCv, false>), dim3(grid), dim3(256), 0, s, a); \
   } while (0)
+#define T41RX_BACK_PAR()                                                                                            \
+  do {                                                                                                              \
+    if (a.q15)                                                                                                      \
+      hipLaunchKernelGGL((rx512_kernel<kModeSsb, false, 2, false, false, true, true>), dim3(grid_par), dim3(256), 0, s, a); \
+    else                                                                                                            \
+      hipLaunchKernelGGL((rx512_kernel<kModeSsb, false, 2, false, false, false, true>), dim3(grid_par), dim3(256), 0, s, a); \
+  } while (0)
   if (mode == T41RX_DEMOD_AM) {
     if (a.agc)
       T41RX_BACK(kModeAm, true);
@@ -2208,10 +2425,11 @@ static hipError_t launch_long(const RxArgs &a, int mode, hipStream_t s) {
       T41RX_BACK(kModeAm, false);
   } else if (a.agc) {
     T41RX_BACK(kModeSsb, true);
-  } else {
-    T41RX_BACK(kModeSsb, false);
+  } else {  // SSB / NFM audio with the fixed gain: the gain law and the demodulators keep no state here
+    T41RX_BACK_PAR();
   }
 #undef T41RX_BACK
+#undef T41RX_BACK_PAR
   return hipGetLastError();
 }
 

@@ -47,6 +47,9 @@ WORKLOADS = {
     "nfm": dict(batch=4096, fft=512, kw=dict(mode=3, FLoCut=200, FHiCut=3000, nfmFilterBW=12000),
                 name="configs[2]: NFM path as the firmware runs it (quadri-correlator + limiter + real overlap-save audio "
                      "filter), 4096 channels x 2048 samples per frame"),
+    "nfm_atan": dict(batch=4096, fft=512, kw=dict(mode=3, FLoCut=200, FHiCut=3000, nfmFilterBW=12000, nfm_demod=1),
+                     name="configs[2] as BASELINE words it: the atan2 discriminator + de-emphasis the reference's source keeps "
+                          "commented out (Demod.cpp:148-197, 324-392; t41rx_params.nfm_demod = 1), 4096 channels x 2048 samples per frame"),
     "am": dict(batch=4096, fft=512, kw=dict(mode=2, FLoCut=-3000, FHiCut=3000),
                name="AM path (AlphaBetaMag envelope, DC block, biquad low-pass; Process.cpp:697-707), 4096 channels x 2048 "
                     "samples per frame"),

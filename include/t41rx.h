@@ -74,6 +74,11 @@ typedef struct t41rx_params {
   int32_t CWFreqShift;             /* Freq_Shift.cpp:113-116 */
   int32_t am_lpf_f0;               /* cutoff biquad_lowpass1 was designed for at boot, T41_SDR.ino:560-566 */
   int32_t AGC_thresh;              /* bands[currentBand].AGC_thresh [dB], SDT.h:190, DSP_Fn.cpp:408 */
+  int32_t nfm_demod;               /* NFM discriminator: 0 = nfmdemod() (quadri-correlator) + limiter, what the
+                                      firmware runs (Process.cpp:716-727); 1 = the alternative its source keeps
+                                      commented out: fmdemod_atan_cf (Demod.cpp:368-392, ApproxAtan2 :148-197 with its
+                                      2 pi for pi / 2 as written) + limiter + deemphasis_nfm_ff applied block-wise
+                                      (Demod.cpp:324-344, Process.cpp:734-735).  fft_length 512 only. */
 } t41rx_params;
 
 typedef struct t41rx_ctx t41rx_ctx; /* opaque: coefficient arrays + per-channel state + device buffers */

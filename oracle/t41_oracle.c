@@ -57,6 +57,7 @@ void t41o_default_params(t41o_params *p) {
   p->CWFreqShift = 750;
   p->am_lpf_f0 = 3000;            /* boot band 40M LSB -200/-3000, T41_SDR.ino:560-563 */
   p->AGC_thresh = 20;             /* bands[] "AGC" column, T41_SDR.ino:145-168 */
+  p->nfm_demod = 0;               /* the live code path, Process.cpp:716 */
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -468,6 +469,7 @@ struct t41o_channel {
   float wold;                         /* Process.cpp:73 */
   float lp1_state[4];                 /* biquad_lowpass1_state, T41_SDR.ino:373 */
   float nfm_last_i, nfm_last_q;       /* Demod.cpp:221-222 */
+  float nfm_last_phase;               /* fmdemod_atan_cf's static, Demod.cpp:373 */
   /* AGC() statics and globals, DSP_Fn.cpp:28-36, 481-492 */
   uint8_t agc_decay_type, agc_state;
   float *agc_abs_ring, *agc_ring;     /* [RB_SIZE], [2*RB_SIZE] */
@@ -571,6 +573,7 @@ void t41o_channel_reset(t41o_channel *ch) {
   ch->wold = 0.0f;
   memset(ch->lp1_state, 0, sizeof(ch->lp1_state));
   ch->nfm_last_i = ch->nfm_last_q = 0.0f;
+  ch->nfm_last_phase = 0.0f;
   /* DSP_Fn.cpp:32-36, 481-492 */
   ch->agc_decay_type = 0;
   ch->agc_state = 0;
@@ -659,6 +662,66 @@ static void nfmdemod(t41o_channel *ch, const float *input, float *output, int in
   }
   ch->nfm_last_i = input[input_size - 2];
   ch->nfm_last_q = input[input_size - 1];
+}
+
+/* ---- the NFM variant the reference keeps commented out (nfm_demod = 1): parity for it is pinned by
+ * this restatement alone -- the firmware never ran it as written here ---- */
+#define T41O_PI 3.1415926535897932384626433832795f  /* FIR.h:10 */
+#define T41O_TPI 6.283185307179586476925286766559f  /* FIR.h:12-13: TPI = TWO_PI */
+
+/* Utility.cpp:298-302 */
+static float ApproxAtan(float z) {
+  const float n1 = 0.97239411f;
+  const float n2 = -0.19194795f;
+  return (n1 + n2 * z * z) * z;
+}
+
+/* Demod.cpp:148-197.  Where pi/2 is meant (|y| >= |x|, and x == 0) the source adds TPI = 2 pi
+ * (SURVEY App. C #8): kept as written. */
+static float ApproxAtan2(float y, float x) {
+  if (x != 0.0f) {
+    if (fabsf(x) > fabsf(y)) {
+      const float z = y / x;
+      if (x > 0.0f) return ApproxAtan(z);
+      else if (y >= 0.0f) return ApproxAtan(z) + T41O_PI;
+      else return ApproxAtan(z) - T41O_PI;
+    } else {
+      const float z = x / y;
+      if (y > 0.0f) return -ApproxAtan(z) + T41O_TPI;
+      else return -ApproxAtan(z) - T41O_TPI;
+    }
+  } else {
+    if (y > 0.0f) return T41O_TPI;
+    else if (y < 0.0f) return -T41O_TPI;
+  }
+  return 0.0f;
+}
+
+/* Demod.cpp:368-392 */
+static void fmdemod_atan_cf(t41o_channel *ch, const float *input, float *output, int input_size) {
+  float phase, dphase;
+  for (int i = 0; i < input_size; i++) {
+    phase = ApproxAtan2(input[i * 2 + 1], input[i * 2]);
+    dphase = phase - ch->nfm_last_phase;
+    if (dphase < -T41O_PI) dphase += 2 * T41O_PI;
+    if (dphase > T41O_PI) dphase -= 2 * T41O_PI;
+    output[i] = dphase / T41O_PI;
+    ch->nfm_last_phase = phase;
+  }
+}
+
+/* Demod.cpp:324-344: deemphasis_nfm_predefined_fir_24000 and the block-wise FIR as written: only
+ * input_size - taps_length outputs are produced, the rest of `output` is left as it was */
+static const float deemphasis_nfm_fir_24000[81] = {
+  0.000481913, -0.000816211, -0.00205384, -0.00264474, -0.00258229, -0.00247939, -0.00305299, -0.00448116, -0.00620366, -0.00737591, -0.00761292, -0.00737176, -0.0075984, -0.00890065, -0.0109592, -0.0127338, -0.0133493, -0.0129165, -0.0125289, -0.013351, -0.0155348, -0.0179452, -0.0190498, -0.0183068, -0.016827, -0.0165808, -0.0186455, -0.0219659, -0.0238965, -0.0223995, -0.0182146, -0.0149414, -0.0163342, -0.0223751, -0.0271497, -0.020849, 0.00446391, 0.0485999, 0.100768, 0.143223, 0.159583, 0.143223, 0.100768, 0.0485999, 0.00446391, -0.020849, -0.0271497, -0.0223751, -0.0163342, -0.0149414, -0.0182146, -0.0223995, -0.0238965, -0.0219659, -0.0186455, -0.0165808, -0.016827, -0.0183068, -0.0190498, -0.0179452, -0.0155348, -0.013351, -0.0125289, -0.0129165, -0.0133493, -0.0127338, -0.0109592, -0.00890065, -0.0075984, -0.00737176, -0.00761292, -0.00737591, -0.00620366, -0.00448116, -0.00305299, -0.00247939, -0.00258229, -0.00264474, -0.00205384, -0.000816211, 0.000481913
+};
+static void deemphasis_nfm_ff(const float *input, float *output, int input_size) {
+  const int taps_length = 81;
+  for (int i = 0; i < input_size - taps_length; i++) {
+    float acc = 0;
+    for (int ti = 0; ti < taps_length; ti++) acc += deemphasis_nfm_fir_24000[ti] * input[i + ti];
+    output[i] = acc;
+  }
 }
 
 /* DSP_Fn.cpp:494-502 (AGCMode == 0): fixed_gain = 20 (DSP_Fn.cpp:453) on the upper half */
@@ -1045,12 +1108,19 @@ int t41o_process_frame(t41o_channel *ch, const t41o_params *p, const t41o_coeffs
       memcpy(fL, fR, sizeof(float) * (size_t)D);
       break;
     case T41O_DEMOD_NFM:
-      nfmdemod(ch, &FFT_buffer[N], fL, D); /* Process.cpp:716 */
+      if (p->nfm_demod == 1) fmdemod_atan_cf(ch, &FFT_buffer[N], fL, D); /* the commented-out alternative */
+      else nfmdemod(ch, &FFT_buffer[N], fL, D); /* Process.cpp:716 */
       for (int i = 1; i < D; i++) {        /* Process.cpp:719-727 (starts at 1) */
         float tmp = fL[i];
         tmp = (1 < tmp) ? 1 : tmp;
         tmp = (-1 > tmp) ? -1 : tmp;
         fL[i] = tmp;
+      }
+      if (p->nfm_demod == 1) {
+        /* Process.cpp:734-735 uncommented: float_buffer_R still holds the decimated Q samples, so the
+         * last 81 "de-emphasised" samples of every block are those (the buzz the comment mentions) */
+        deemphasis_nfm_ff(fL, fR, D);
+        memcpy(fL, fR, sizeof(float) * (size_t)D);
       }
       break;
   }

@@ -59,6 +59,9 @@ typedef struct {
   int32_t CWFreqShift;      /* Freq_Shift.cpp:113-116 */
   int32_t am_lpf_f0;        /* cutoff the AM biquad was designed for at boot, T41_SDR.ino:560-566 (3000) */
   int32_t AGC_thresh;       /* bands[currentBand].AGC_thresh, SDT.h:190 (20 in every bands[] row) */
+  int32_t nfm_demod;        /* 0 = nfmdemod() + limiter, what the firmware runs (Process.cpp:716-727); 1 = the variant
+                               the source keeps commented out: fmdemod_atan_cf (Demod.cpp:368-392, ApproxAtan2
+                               Demod.cpp:148-197) + limiter + deemphasis_nfm_ff (Demod.cpp:328-344, Process.cpp:734-735) */
 } t41o_params;
 
 /* what AGCPrep() + AGCLoadValues() (DSP_Fn.cpp:368-468) leave in the AGC globals, as f32 */

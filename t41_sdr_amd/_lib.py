@@ -33,6 +33,7 @@ class Params(C.Structure):
         ("CWFreqShift", C.c_int32),
         ("am_lpf_f0", C.c_int32),
         ("AGC_thresh", C.c_int32),
+        ("nfm_demod", C.c_int32),
     ]
 
 

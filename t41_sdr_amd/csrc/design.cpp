@@ -190,6 +190,9 @@ void agc_constants(const t41rx_params &p, float *out) {
 
 }  // namespace
 
+const float kDeemphFir24000[kDeemphTaps] = {
+    0.000481913f, -0.000816211f, -0.00205384f, -0.00264474f, -0.00258229f, -0.00247939f, -0.00305299f, -0.00448116f, -0.00620366f, -0.00737591f, -0.00761292f, -0.00737176f, -0.0075984f, -0.00890065f, -0.0109592f, -0.0127338f, -0.0133493f, -0.0129165f, -0.0125289f, -0.013351f, -0.0155348f, -0.0179452f, -0.0190498f, -0.0183068f, -0.016827f, -0.0165808f, -0.0186455f, -0.0219659f, -0.0238965f, -0.0223995f, -0.0182146f, -0.0149414f, -0.0163342f, -0.0223751f, -0.0271497f, -0.020849f, 0.00446391f, 0.0485999f, 0.100768f, 0.143223f, 0.159583f, 0.143223f, 0.100768f, 0.0485999f, 0.00446391f, -0.020849f, -0.0271497f, -0.0223751f, -0.0163342f, -0.0149414f, -0.0182146f, -0.0223995f, -0.0238965f, -0.0219659f, -0.0186455f, -0.0165808f, -0.016827f, -0.0183068f, -0.0190498f, -0.0179452f, -0.0155348f, -0.013351f, -0.0125289f, -0.0129165f, -0.0133493f, -0.0127338f, -0.0109592f, -0.00890065f, -0.0075984f, -0.00737176f, -0.00761292f, -0.00737591f, -0.00620366f, -0.00448116f, -0.00305299f, -0.00247939f, -0.00258229f, -0.00264474f, -0.00205384f, -0.000816211f, 0.000481913f};
+
 bool params_valid(const t41rx_params &p, const char **why) {
   auto fail = [&](const char *m) {
     if (why) *why = m;
@@ -210,6 +213,7 @@ bool params_valid(const t41rx_params &p, const char **why) {
   if (p.am_lpf_f0 <= 0) return fail("am_lpf_f0 must be > 0");
   if (p.AGCMode < 0 || p.AGCMode > 4) return fail("AGCMode must be 0 (off) .. 4 (fast)");
   if (p.AGC_thresh < -40 || p.AGC_thresh > 120) return fail("AGC_thresh out of -40..120 dB");
+  if (p.nfm_demod < 0 || p.nfm_demod > 1) return fail("nfm_demod must be 0 (quadri-correlator) or 1 (atan2 + de-emphasis)");
   return true;
 }
 
@@ -293,6 +297,7 @@ int design_blob(const t41rx_params &p, void *blob, size_t blob_bytes) {
     }
     s[kScSideTone] = (float)side;
   }
+  s[kScNfmDemod] = (float)p.nfm_demod;
   return T41RX_OK;
 }
 

@@ -130,6 +130,7 @@ int upload_coeffs(t41rx_ctx *ctx) {
   std::memcpy(dc.lp1, v.lp1, sizeof(float) * 5);
   std::memcpy(dc.sc, v.scalars, sizeof(float) * kNumScalars);
   std::memcpy(dc.agc, v.agc, sizeof(float) * kNumAgc);
+  std::memcpy(dc.deemph, kDeemphFir24000, sizeof(float) * kDeemphTaps);
   HIP_TRY(hipMemcpy(ctx->d_coef, &dc, sizeof(dc), hipMemcpyHostToDevice));
 
   const int R = N / 512;  // 2048-sample segments per frame
@@ -494,6 +495,8 @@ int process_device_impl(t41rx_ctx *ctx, const float *dI, const float *dQ, float 
   }
   a.q15 = q15 ? 1 : 0;
   a.nco_rd = ctx->nco_sel;
+  a.nfm_atan = (ctx->params.mode == T41RX_DEMOD_NFM && ctx->params.nfm_demod == 1) ? 1 : 0;
+  if (a.nfm_atan && seg > 1) return fail(T41RX_ERR_UNSUPPORTED, "nfm_demod = 1 is built for fft_length 512");
   {
     // Segment-parallel kernels of the long-FFT pipeline: about 4096 wave slots (256 CUs x 16) to
     // fill; a wave that starts inside the call pays one extra sub-block to rebuild its filter

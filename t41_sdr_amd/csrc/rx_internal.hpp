@@ -32,7 +32,11 @@ enum Scalar {
   kScOutScale = 6,    // DF * VolumeToAmplification(audioVolume), Process.cpp:929
   kScIqCorrOn = 7,    // 1 when mode in {USB, LSB, AM}, Process.cpp:165-173
   kScSideTone = 8,    // sideToneShift [Hz], Freq_Shift.cpp:108-120
+  kScNfmDemod = 9,    // t41rx_params::nfm_demod (0 quadri-correlator, 1 atan2 + de-emphasis)
 };
+// deemphasis_nfm_predefined_fir_24000 (Demod.cpp:324-325), a fixed table of the reference
+constexpr int kDeemphTaps = 81;
+extern const float kDeemphFir24000[kDeemphTaps];
 // what AGCPrep() + AGCLoadValues() (DSP_Fn.cpp:368-468) leave in the AGC globals
 constexpr int kNumAgc = 16;
 enum AgcConst {
@@ -79,6 +83,7 @@ struct DevCoef {
   float lp1[8];    // 5 used
   float sc[16];    // Scalar enum
   float agc[16];   // AgcConst enum
+  float deemph[96];  // kDeemphFir24000, zero padded (scalar loads come in chunks of 16)
 };
 
 // per-channel NCO constants, recomputed on the host when NCOFreq changes (set_nco_freq)
@@ -102,6 +107,7 @@ constexpr int kMiscDc = 0;      // DC-HP d1 (HP_DC_Butter_state2[0]); [1] = d2 (
 constexpr int kMiscWold = 2;    // AM DC-block wold, Process.cpp:73
 constexpr int kMiscNfmI = 4;    // nfmdemod last_sample_i/q, Demod.cpp:221-222
 constexpr int kMiscNfmQ = 5;
+constexpr int kMiscNfmPhase = 6; // fmdemod_atan_cf's last_phase (nfm_demod = 1), Demod.cpp:373
 constexpr int kMiscLp1 = 8;     // biquad_lowpass1_state[4]
 constexpr int kMiscMaxSqAve = 12; // audioMaxSquaredAve, Process.cpp:570
 constexpr int kStNco = 200;     // 8 floats = two NcoState (16 B each); FFT_LENGTH 512 uses the first, the long

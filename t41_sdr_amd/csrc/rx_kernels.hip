@@ -1704,6 +1704,80 @@ __global__ __launch_bounds__(Geo<PART>::kWaves * 64, 4) void rx512_kernel(const 
           au[rd][0] = a0;
           au[rd][1] = a1;
         }
+        if (PART == 0 && a.nfm_atan) {
+          // ---- nfm_demod = 1, the alternative the reference keeps commented out: fmdemod_atan_cf
+          // (Demod.cpp:368-392) with ApproxAtan2 (Demod.cpp:148-197, its 2 pi for pi / 2 as written),
+          // the limiter, then deemphasis_nfm_ff applied block-wise (Demod.cpp:328-344, Process.cpp:
+          // 734-735): only the first 256 - 81 samples of a block are filtered, the rest of the
+          // destination buffer still holds the decimated Q samples.
+#pragma clang fp contract(off)
+          constexpr float kPi = 3.1415926535897932384626433832795f, kTpi = 6.283185307179586476925286766559f;
+          auto atan_poly = [](float z) { return (0.97239411f + -0.19194795f * z * z) * z; };  // ApproxAtan, Utility.cpp:298-302
+          auto atan2_as_written = [&](float y, float x) {
+            const bool wide = fabsf(x) > fabsf(y);
+            const float z = wide ? y / x : x / y;
+            const float t = atan_poly(z);
+            const float r_wide = (x > 0.0f) ? t : (y >= 0.0f ? t + kPi : t - kPi);
+            const float r_tall = (y > 0.0f) ? -t + kTpi : -t - kTpi;
+            const float r_axis = (y > 0.0f) ? kTpi : (y < 0.0f ? -kTpi : 0.0f);
+            return (x != 0.0f) ? (wide ? r_wide : r_tall) : r_axis;
+          };
+          float ph[2][2];
+  #pragma unroll
+          for (int rd = 0; rd < 2; ++rd)
+  #pragma unroll
+            for (int e = 0; e < 2; ++e) ph[rd][e] = atan2_as_written(y2[rd][e].y, y2[rd][e].x);
+          const float last_phase = st[kStMisc + kMiscNfmPhase];
+  #pragma unroll
+          for (int rd = 0; rd < 2; ++rd) {
+            float prev = lane_up1(ph[rd][1]);
+            if (lane == 0) prev = (rd == 0) ? last_phase : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ph[0][1]), 63));
+            float d[2] = {ph[rd][0] - prev, ph[rd][1] - ph[rd][0]};
+  #pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              if (d[e] < -kPi) d[e] += 2 * kPi;
+              if (d[e] > kPi) d[e] -= 2 * kPi;
+              float o = d[e] / kPi;
+              if (!(rd == 0 && e == 0 && lane == 0)) {  // Process.cpp:719-727: the limiter skips sample 0
+                o = (1.0f < o) ? 1.0f : o;
+                o = (-1.0f > o) ? -1.0f : o;
+              }
+              au[rd][e] = o;
+            }
+          }
+          if (lane == 63) st[kStMisc + kMiscNfmPhase] = ph[1][1];
+          // de-emphasis: out[i] = sum_ti taps[ti] * in[i + ti], i < 175; samples through LDS in natural order
+          float *ds = lds + kScr;
+          wave_sync();
+  #pragma unroll
+          for (int rd = 0; rd < 2; ++rd) *reinterpret_cast<float2 *>(ds + 128 * rd + 2 * lane) = make_float2(au[rd][0], au[rd][1]);
+          wave_sync();
+  #pragma unroll
+          for (int rd = 0; rd < 2; ++rd) {
+            const int m0 = 128 * rd + 2 * lane;  // my samples m0, m0 + 1 share the window in[m0 .. m0 + 81]
+            float acc0 = 0.0f, acc1 = 0.0f;      // taps in ascending order, separate multiply and add, as the reference's loop
+            float tp[96];
+  #pragma unroll
+            for (int c = 0; c < 96; c += 16) {
+              float chunk[16];
+              load_taps<16>(chunk, (CFloatPtr)cf0->deemph + c);
+  #pragma unroll
+              for (int k = 0; k < 16; ++k) tp[c + k] = chunk[k];
+  #pragma unroll
+              for (int jj = c / 2; jj < c / 2 + 8; ++jj) {
+                if (2 * jj > kDeemphTaps) continue;  // pairs (in[m0 + 2 jj], in[m0 + 2 jj + 1]), jj = 0..40
+                const float2 w = *reinterpret_cast<const float2 *>(ds + m0 + 2 * jj);
+                if (2 * jj < kDeemphTaps) acc0 += tp[2 * jj] * w.x;
+                if (jj > 0) acc1 += tp[2 * jj - 1] * w.x;
+                if (2 * jj + 1 < kDeemphTaps) acc0 += tp[2 * jj + 1] * w.y;
+                if (2 * jj < kDeemphTaps) acc1 += tp[2 * jj] * w.y;
+              }
+            }
+            au[rd][0] = (m0 < D - kDeemphTaps) ? acc0 : y2[rd][0].y;
+            au[rd][1] = (m0 + 1 < D - kDeemphTaps) ? acc1 : y2[rd][1].y;
+          }
+          wave_sync();
+        }
         // Demod.cpp:232-233 keeps floats [input_size-2], [input_size-1] of the interleaved buffer
         // as "last sample": that is complex sample 127 (m = 127: round 0, lane 63, odd), not 255
         // (frame of 256 seg samples: complex sample 128 seg - 1 = the last one of segment seg/2 - 1)

@@ -56,6 +56,7 @@ struct RxArgs {
   float iq_phase;          // sc[kScIqPhase]
   int iq_corr_on;          // sc[kScIqCorrOn] != 0
   int q15;                 // 1: I, Q, out point at int16 (q15) samples instead of f32 (Process.cpp:102-111, 936)
+  int nfm_atan;            // NFM: 1 = atan2 discriminator + block-wise de-emphasis (t41rx_params::nfm_demod)
   int seg_run;             // long FFT, segment-parallel kernels: consecutive segments one wave runs
   int nco_rd;              // long FFT: which of the two NcoState copies holds the call's start state (the other is written)
 };

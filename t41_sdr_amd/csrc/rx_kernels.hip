@@ -949,9 +949,13 @@ constexpr int kModeSsb = 0, kModeAm = 1, kModeNfm = 2;  // kernel template MODE
 #ifndef T41RX_RESIDENT
 #define T41RX_RESIDENT 1  // 0 (experiments): the fused kernel with the 4-wave geometry and per-frame HBM state
 #endif
-template <int PART>
+// AGC on (PART 0): back to 4-wave workgroups and per-frame state in HBM.  The serial gain law
+// runs on one wave of the workgroup between two workgroup barriers; with 16 waves behind one
+// barrier the whole CU stops for every chain (47.6 us per 4096 x 2048 frame), four independent
+// workgroups per CU keep the other twelve waves busy (40.6 us).
+template <int PART, bool AGC = false>
 struct Geo {
-  static constexpr bool kResident = (PART == 0) && T41RX_RESIDENT;
+  static constexpr bool kResident = (PART == 0) && !AGC && T41RX_RESIDENT;
   static constexpr int kWaves = kResident ? 16 : 4;
   static constexpr int kTab = kResident ? 1024 : kLdsTabFloats;
   static constexpr int kTw1 = kResident ? 0 : kLdsTabTw1;        // float2 units within the tables
@@ -984,9 +988,9 @@ static_assert(!Geo<0>::kResident || (Geo<0>::kH1 + 24 <= Geo<0>::kSlice && Geo<0
 // state is written by the wave that READ it (the one that starts the call), from the call's last
 // samples in the same way: a wave of a later run may execute before that one has started.
 template <int MODE, bool DEBUG, int PART, bool PLAIN, bool AGC = false, bool WQ15 = false, bool SEGPAR = false>
-__global__ __launch_bounds__(Geo<PART>::kWaves * 64, 4) void rx512_kernel(const RxArgs a) {
+__global__ __launch_bounds__((Geo<PART, AGC>::kWaves * 64), 4) void rx512_kernel(const RxArgs a) {
   static_assert(!SEGPAR || (PART == 1 && MODE != kModeNfm) || (PART == 2 && MODE == kModeSsb && !AGC), "SEGPAR variants");
-  typedef Geo<PART> G;
+  typedef Geo<PART, AGC> G;
   constexpr bool KEEP = G::kResident;  // streaming state stays on chip across the frames of a launch
   constexpr int NW = G::kWaves;
   constexpr int kX = G::kX, kY1 = G::kY1, kScr = G::kScr, kI1 = G::kI1;
@@ -2412,9 +2416,10 @@ static hipError_t launch512(const RxArgs &a, hipStream_t s, bool debug) {
   // One 16-wave workgroup per CU (all 160 KiB of LDS, declared statically by the kernel): a
   // 4096-channel batch is one full, balanced wave of work on 256 CUs, and every wave keeps its
   // channel for all the frames of the launch.
-  constexpr int NW = Geo<0>::kWaves;
-  const dim3 grid((a.nchan + NW - 1) / NW), block(NW * 64);
-#define T41RX_GO(DBG, PLN, AGCv, Q15v) hipLaunchKernelGGL((rx512_kernel<MODE, DBG, 0, PLN, AGCv, Q15v>), grid, block, 0, s, a)
+  // (AGC on: 4-wave workgroups, see Geo)
+#define T41RX_GO(DBG, PLN, AGCv, Q15v)                                                                   \
+  hipLaunchKernelGGL((rx512_kernel<MODE, DBG, 0, PLN, AGCv, Q15v>),                                      \
+                     dim3((a.nchan + Geo<0, AGCv>::kWaves - 1) / Geo<0, AGCv>::kWaves), dim3(Geo<0, AGCv>::kWaves * 64), 0, s, a)
   if (a.q15) {  // the firmware's q15 sample format either side (no debug taps: refused by the host)
     if (a.agc) {
       if (a.plain)

@@ -1,0 +1,38 @@
+#!/bin/bash
+# Round profiles (GPU box): for each bench workload a rocprofv3 kernel-trace summary and the two HBM
+# PMC passes (FETCH_SIZE, WRITE_SIZE: separate processes, counters only), plus the SQ utilisation
+# passes for the headline workload.  Output under gpurun_out/profile_<tag>/; tools/collect_profiles.py
+# copies the summaries into profiles/ and rewrites profiles/hbm_traffic.json.
+# usage: tools/profile_round.sh TAG [workload ...]
+TAG=$1; shift
+WL=${@:-ssb nfm nfm_atan am ssb_agc ssb_q15 fft4096}
+export TMPDIR=/tmp
+OUT=$GRAFT_REPO_ROOT/gpurun_out/profile_$TAG
+mkdir -p $OUT
+cd /tmp
+for W in $WL; do
+  echo "== $W"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$W/trace -o t -- python3 $GRAFT_REPO_ROOT/bench.py --workload $W --steps 30 --warmup 5 --no-cpu-baseline > $OUT/$W.trace.log 2>&1 || echo "trace $W failed"
+  for C in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $C --output-format csv -d $OUT/$W/$C -o p -- python3 $GRAFT_REPO_ROOT/bench.py --workload $W --steps 6 --warmup 2 --no-cpu-baseline > $OUT/$W.$C.log 2>&1 || echo "pmc $C $W failed"
+  done
+  tail -1 $OUT/$W.trace.log | cut -c1-200
+done
+# SQ passes for the headline workload
+PASSES=(
+ "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES"
+ "SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS"
+ "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"
+)
+i=0
+for CNT in "${PASSES[@]}"; do
+  i=$((i+1))
+  rocprofv3 --pmc $CNT --output-format csv -d $OUT/ssb/sq$i -o p -- python3 $GRAFT_REPO_ROOT/bench.py --workload ssb --steps 6 --warmup 2 --no-cpu-baseline > $OUT/ssb.sq$i.log 2>&1 || echo "sq pass $i failed"
+done
+# keep the merge small: per-dispatch traces are not needed, and of the counter CSVs only our kernels' rows
+find $OUT -name "*kernel_trace.csv" -delete
+for F in $(find $OUT -name "*counter_collection.csv"); do
+  (head -1 $F; grep "t41::" $F) > $F.tmp && mv $F.tmp $F
+done
+find $OUT -name "*.csv" -size +8M -delete
+echo done

@@ -190,6 +190,21 @@ int t41rx_set_debug_taps(t41rx_ctx *ctx, float *d_post_nco, float *d_dec, float 
  * code and stays with the caller.  fft_length 512, f32 entry points only.  max_frames as above. */
 int t41rx_set_audio_spectrum(t41rx_ctx *ctx, float *d_spect, float *d_max, int max_frames);
 
+/* ---- the display FFT: what ShowSpectrum() draws from (FFT.cpp:67-251) ----
+ * CalcZoom1Magn() (spectrumZoom = 0: Hann-windowed 512-point FFT of the frame's first 512 I/Q samples
+ * after gains, DC high-pass and IQ correction, Process.cpp:185-187) or ZoomFFTExe() (spectrumZoom
+ * 1..4 = 2x..16x: Fs/4 shift, 4-stage elliptic IIR mag_coeffs[zoom], 4-tap decimating FIR by 2^zoom,
+ * 512-sample ring, window, FFT; Process.cpp:211-215), both up to FFT_spec[512] (squared magnitudes,
+ * halves swapped so that DC sits at index 256) and the display's low-pass memory FFT_spec_old[512].
+ * The pixel mapping behind them (log10f_fast, display scale, pixel offsets) stays with the caller.
+ * Device pointers, both NULL = off (the default).  While set, every processed frame is treated as
+ * one with updateDisplayFlag == 1 and writes
+ *   d_spec     : [n_channels][n_frames][512]  FFT_spec
+ *   d_spec_old : [n_channels][n_frames][512]  FFT_spec_old
+ * Setting it (or changing spectrumZoom) starts from cleared zoom filters, ring and low-pass memory.
+ * fft_length 512, f32 entry points only; max_frames as for the stage taps. */
+int t41rx_set_display_spectrum(t41rx_ctx *ctx, float *d_spec, float *d_spec_old, int spectrumZoom, int max_frames);
+
 #ifdef __cplusplus
 }
 #endif

@@ -487,6 +487,14 @@ struct t41o_channel {
   float audioSpectBuffer[1024];
   float audioMaxSquared, audioMaxSquaredAve;
   uint32_t AudioMaxIndex;
+  /* display FFT (FFT.cpp): spectrumZoom (-1 = not computed), the zoom filters' state, the ring, the low-pass memory */
+  int display_zoom;
+  float zoom_iir_I_state[16], zoom_iir_Q_state[16];   /* IIR_biquad_Zoom_FFT_[IQ]_state, T41_SDR.ino:378-379 */
+  float zoom_fir_coeffs[4];                           /* Fir_Zoom_FFT_Decimate_coeffs, FFT.cpp:20 */
+  float *zoom_fir_I_state, *zoom_fir_Q_state;         /* 3 + frame_len */
+  float FFT_ring_buffer_x[512], FFT_ring_buffer_y[512];
+  int zoom_sample_ptr;
+  float FFT_spec[512], FFT_spec_old[512];
 };
 
 static float *fzalloc(size_t n) { return (float *)calloc(n, sizeof(float)); }
@@ -515,6 +523,9 @@ t41o_channel *t41o_channel_create(int fft_length) {
   ch->float_buffer_R_EX = fzalloc((size_t)L);
   ch->FFT_buffer = fzalloc((size_t)(2 * N));
   ch->iFFT_buffer = fzalloc((size_t)(2 * N + 1));
+  ch->zoom_fir_I_state = fzalloc((size_t)(3 + L));
+  ch->zoom_fir_Q_state = fzalloc((size_t)(3 + L));
+  ch->display_zoom = -1;
   ch->tap_ncoI = fzalloc((size_t)L);
   ch->tap_ncoQ = fzalloc((size_t)L);
   ch->tap_decI = fzalloc((size_t)D);
@@ -606,6 +617,8 @@ int t41o_channel_tap(const t41o_channel *ch, int which, float *dst, int maxlen) 
     case T41O_TAP_AGC_VOLTS: src = ch->tap_volts; n = ch->D; break;
     case T41O_TAP_AUDIO_SPECT: src = ch->audioSpectBuffer; n = 1024; break;
     case T41O_TAP_AGC_EDGES: src = ch->agc_edges; n = 25; break;
+    case T41O_TAP_FFT_SPEC: src = ch->FFT_spec; n = 512; break;
+    case T41O_TAP_FFT_SPEC_OLD: src = ch->FFT_spec_old; n = 512; break;
     case T41O_TAP_AUDIO_MAX: {
       float t[3] = {ch->audioMaxSquared, (float)ch->AudioMaxIndex, ch->audioMaxSquaredAve};
       int m = maxlen < 3 ? maxlen : 3;
@@ -622,6 +635,118 @@ int t41o_channel_tap(const t41o_channel *ch, int which, float *dst, int maxlen) 
 /* ------------------------------------------------------------------------------------------
  * The block function
  * ---------------------------------------------------------------------------------------- */
+
+/* ---- display FFT (FFT.cpp:28-251), up to FFT_spec / FFT_spec_old; the pixel mapping that follows
+ * (log10f_fast, display scale, pixel offsets) is display code and is not restated ---- */
+#define SPECTRUM_RES 512 /* Display.h:12 */
+/* mag_coeffs[1..4] (FIR.cpp:582-680): 4-stage elliptic low-passes for 2x .. 16x (MAX_ZOOM_ENTRIES = 5, ButtonProc.h:6) */
+static const float mag_coeffs_1_4[4][20] = {
+    {0.228454526413293696f, 0.077639329099949764f, 0.228454526413293696f, 0.635534925142242080f, -0.170083307068779194f, 0.436788292542003964f, 0.232307972937606161f, 0.436788292542003964f, 0.365885230717786780f, -0.471769788739400842f, 0.535974654742658707f, 0.557035600464780845f, 0.535974654742658707f, 0.125740787233286133f, -0.754725697183384336f, 0.501116342273565607f, 0.914877831284765408f, 0.501116342273565607f, 0.013862536615004284f, -0.930973052446900984f},
+    {0.182208761527446556f, -0.222492493114674145f, 0.182208761527446556f, 1.326111070880959810f, -0.468036100821178802f, 0.337123762652097259f, -0.366352718812586853f, 0.337123762652097259f, 1.337053579516321200f, -0.644948386007929031f, 0.336163175380826074f, -0.199246162162897811f, 0.336163175380826074f, 1.354952684569386670f, -0.828032873168141115f, 0.178588201750411041f, 0.207271695028067304f, 0.178588201750411041f, 1.386486967455699220f, -0.950935065984588657f},
+    {0.185643392652478922f, -0.332064345389014803f, 0.185643392652478922f, 1.654637402827731090f, -0.693859842743674182f, 0.327519300813245984f, -0.571358085216950418f, 0.327519300813245984f, 1.715375037176782860f, -0.799055553586324407f, 0.283656142708241688f, -0.441088976843048652f, 0.283656142708241688f, 1.778230635987093860f, -0.904453944560528522f, 0.079685368654848945f, -0.011231810140649204f, 0.079685368654848945f, 1.825046003243238070f, -0.973184930412286708f},
+    {0.194769868656866380f, -0.379098413160710079f, 0.194769868656866380f, 1.824436402073870810f, -0.834877726226893380f, 0.333973874901496770f, -0.646106479315673776f, 0.333973874901496770f, 1.871892825636887640f, -0.893734096124207178f, 0.272903880596429671f, -0.513507745397738469f, 0.272903880596429671f, 1.918161772571113750f, -0.950461788366234739f, 0.053535383722369843f, -0.069683422367188122f, 0.053535383722369843f, 1.948900719896301760f, -0.986288064973853129f},
+};
+
+/* ZoomFFTPrep(), FFT.cpp:35-56 */
+int t41o_channel_set_display(t41o_channel *ch, int spectrumZoom) {
+  if (spectrumZoom < -1 || spectrumZoom > 4) return -1;
+  if (ch->N != 512) return -2; /* the display code is written for the 2048-sample frame */
+  ch->display_zoom = spectrumZoom;
+  memset(ch->zoom_iir_I_state, 0, sizeof(ch->zoom_iir_I_state));
+  memset(ch->zoom_iir_Q_state, 0, sizeof(ch->zoom_iir_Q_state));
+  memset(ch->zoom_fir_I_state, 0, sizeof(float) * (size_t)(3 + ch->L));
+  memset(ch->zoom_fir_Q_state, 0, sizeof(float) * (size_t)(3 + ch->L));
+  memset(ch->FFT_ring_buffer_x, 0, sizeof(ch->FFT_ring_buffer_x));
+  memset(ch->FFT_ring_buffer_y, 0, sizeof(ch->FFT_ring_buffer_y));
+  memset(ch->FFT_spec, 0, sizeof(ch->FFT_spec));
+  memset(ch->FFT_spec_old, 0, sizeof(ch->FFT_spec_old));
+  ch->zoom_sample_ptr = 0;
+  if (spectrumZoom > 0) {
+    float Fstop_Zoom = 0.5 * (float)192000 / (1 << spectrumZoom);
+    t41o_CalcFIRCoeffs(ch->zoom_fir_coeffs, 4, Fstop_Zoom, 60, 0, 0.0, (float)192000);
+  }
+  return 0;
+}
+
+/* CalcZoom1Magn(), FFT.cpp:208-251 (spectrumZoom == 0), on float_buffer_L/R before FreqShift1 */
+static void CalcZoom1Magn(t41o_channel *ch, const float *float_buffer_L, const float *float_buffer_R) {
+  float buffer_spec_FFT[2 * SPECTRUM_RES];
+  float spec_help = 0.0;
+  float LPFcoeff = 0.7;
+  for (int i = 0; i < SPECTRUM_RES; i++) {
+    buffer_spec_FFT[i * 2] = float_buffer_L[i] * (0.5 - 0.5 * cos(6.28 * i / SPECTRUM_RES));
+    buffer_spec_FFT[i * 2 + 1] = float_buffer_R[i] * (0.5 - 0.5 * cos(6.28 * i / SPECTRUM_RES));
+  }
+  t41o_cfft_f32(buffer_spec_FFT, SPECTRUM_RES, 0);
+  for (int i = 0; i < SPECTRUM_RES / 2; i++) {
+    ch->FFT_spec[i + SPECTRUM_RES / 2] = (buffer_spec_FFT[i * 2] * buffer_spec_FFT[i * 2] + buffer_spec_FFT[i * 2 + 1] * buffer_spec_FFT[i * 2 + 1]);
+    ch->FFT_spec[i] = (buffer_spec_FFT[(i + SPECTRUM_RES / 2) * 2] * buffer_spec_FFT[(i + SPECTRUM_RES / 2) * 2] +
+                       buffer_spec_FFT[(i + SPECTRUM_RES / 2) * 2 + 1] * buffer_spec_FFT[(i + SPECTRUM_RES / 2) * 2 + 1]);
+  }
+  for (int x = 0; x < SPECTRUM_RES; x++) {
+    spec_help = LPFcoeff * ch->FFT_spec[x] + (1.0 - LPFcoeff) * ch->FFT_spec_old[x];
+    ch->FFT_spec_old[x] = spec_help;
+  }
+}
+
+/* ZoomFFTExe(BUFFER_SIZE * N_BLOCKS), FFT.cpp:67-152 (spectrumZoom != 0), on float_buffer_L/R after FreqShift1 */
+static void ZoomFFTExe(t41o_channel *ch, const float *float_buffer_L, const float *float_buffer_R, int blockSize) {
+  const int spectrumZoom = ch->display_zoom;
+  float LPFcoeff;
+  float onem_LPFcoeff;
+  float *x_buffer = ch->float_buffer_L_EX, *y_buffer = ch->float_buffer_R_EX; /* free at this point (filled later) */
+  float buffer_spec_FFT[2 * SPECTRUM_RES];
+  int sample_no = SPECTRUM_RES;
+  float multiplier;
+  const int M = 1 << spectrumZoom; /* spectrumZoom < 7 */
+  const float *coeffs = mag_coeffs_1_4[spectrumZoom - 1];
+
+  sample_no = blockSize / (1 << spectrumZoom);
+  if (sample_no > SPECTRUM_RES) sample_no = SPECTRUM_RES;
+
+  /* arm_biquad_cascade_df1_f32 with 4 stages */
+  {
+    const float *src = float_buffer_L;
+    for (int st = 0; st < 4; st++) {
+      t41o_biquad_df1_f32(coeffs + 5 * st, ch->zoom_iir_I_state + 4 * st, src, x_buffer, blockSize);
+      src = x_buffer;
+    }
+    src = float_buffer_R;
+    for (int st = 0; st < 4; st++) {
+      t41o_biquad_df1_f32(coeffs + 5 * st, ch->zoom_iir_Q_state + 4 * st, src, y_buffer, blockSize);
+      src = y_buffer;
+    }
+  }
+  t41o_fir_decimate_f32(ch->zoom_fir_coeffs, 4, M, ch->zoom_fir_I_state, x_buffer, x_buffer, blockSize);
+  t41o_fir_decimate_f32(ch->zoom_fir_coeffs, 4, M, ch->zoom_fir_Q_state, y_buffer, y_buffer, blockSize);
+
+  for (int i = 0; i < sample_no; i++) {
+    ch->FFT_ring_buffer_x[ch->zoom_sample_ptr] = x_buffer[i];
+    ch->FFT_ring_buffer_y[ch->zoom_sample_ptr] = y_buffer[i];
+    ch->zoom_sample_ptr++;
+    if (ch->zoom_sample_ptr >= SPECTRUM_RES) ch->zoom_sample_ptr = 0;
+  }
+  multiplier = (float)spectrumZoom;
+  if (spectrumZoom > 3) multiplier = (float)(1 << spectrumZoom);
+  for (int idx = 0; idx < SPECTRUM_RES; idx++) {
+    buffer_spec_FFT[idx * 2 + 0] = multiplier * ch->FFT_ring_buffer_x[ch->zoom_sample_ptr] * (0.5 - 0.5 * cos(6.28 * idx / SPECTRUM_RES));
+    buffer_spec_FFT[idx * 2 + 1] = multiplier * ch->FFT_ring_buffer_y[ch->zoom_sample_ptr] * (0.5 - 0.5 * cos(6.28 * idx / SPECTRUM_RES));
+    ch->zoom_sample_ptr++;
+    if (ch->zoom_sample_ptr >= SPECTRUM_RES) ch->zoom_sample_ptr = 0;
+  }
+  LPFcoeff = 0.7;
+  onem_LPFcoeff = 1.0 - LPFcoeff;
+  t41o_cfft_f32(buffer_spec_FFT, SPECTRUM_RES, 0);
+  for (int i = 0; i < SPECTRUM_RES / 2; i++) {
+    ch->FFT_spec[i + SPECTRUM_RES / 2] = (buffer_spec_FFT[i * 2] * buffer_spec_FFT[i * 2] + buffer_spec_FFT[i * 2 + 1] * buffer_spec_FFT[i * 2 + 1]);
+    ch->FFT_spec[i] = (buffer_spec_FFT[(i + SPECTRUM_RES / 2) * 2] * buffer_spec_FFT[(i + SPECTRUM_RES / 2) * 2] +
+                       buffer_spec_FFT[(i + SPECTRUM_RES / 2) * 2 + 1] * buffer_spec_FFT[(i + SPECTRUM_RES / 2) * 2 + 1]);
+  }
+  for (int i = 0; i < SPECTRUM_RES; i++) {
+    ch->FFT_spec[i] = LPFcoeff * ch->FFT_spec[i] + onem_LPFcoeff * ch->FFT_spec_old[i];
+    ch->FFT_spec_old[i] = ch->FFT_spec[i];
+  }
+}
 
 /* HP_DC_Filter_Coeffs2, FIR.cpp:87-89 */
 static const float HP_DC_Filter_Coeffs2[5] = {
@@ -991,6 +1116,8 @@ int t41o_process_frame(t41o_channel *ch, const t41o_params *p, const t41o_coeffs
     }
   }
 
+  if (ch->display_zoom == 0) CalcZoom1Magn(ch, fL, fR); /* Process.cpp:185-187 */
+
   /* FreqShift1, Freq_Shift.cpp:42-65 */
   for (int i = 0; i < L; i += 4) {
     float hh1, hh2;
@@ -1007,6 +1134,7 @@ int t41o_process_frame(t41o_channel *ch, const t41o_params *p, const t41o_coeffs
     fL[i + 3] = hh1;
     fR[i + 3] = hh2;
   }
+  if (ch->display_zoom > 0) ZoomFFTExe(ch, fL, fR, L); /* Process.cpp:211-215 (updateDisplayFlag == 1) */
   for (int i = 0; i < L; i++) {
     exL[i] = fL[i];
     exR[i] = fR[i];

@@ -155,9 +155,14 @@ enum {
   T41O_TAP_AGC_VOLTS = 6,  /* fft_length/2: `volts` after every sample of the last AGC() call */
   T41O_TAP_AUDIO_SPECT = 7, /* 1024: audioSpectBuffer of the last frame (Process.cpp:550-553) */
   T41O_TAP_AUDIO_MAX = 8,  /* 3: audioMaxSquared, AudioMaxIndex, audioMaxSquaredAve (Process.cpp:569-570) */
-  T41O_TAP_AGC_EDGES = 9   /* 25: since reset, how often AGC state a was followed by b, [5*a + b] (test aid) */
+  T41O_TAP_AGC_EDGES = 9,  /* 25: since reset, how often AGC state a was followed by b, [5*a + b] (test aid) */
+  T41O_TAP_FFT_SPEC = 10,     /* 512: FFT_spec after CalcZoom1Magn() / ZoomFFTExe() of the last frame (FFT.cpp:67-251) */
+  T41O_TAP_FFT_SPEC_OLD = 11  /* 512: FFT_spec_old (the display's low-pass memory) */
 };
 int t41o_channel_tap(const t41o_channel *ch, int which, float *dst, int maxlen);
+/* the display FFT side output (FFT.cpp:67-251): spectrumZoom 0..4 = on (as with updateDisplayFlag == 1
+ * in every frame), -1 = off (the default).  Like ZoomFFTPrep(): zoom filters re-initialised, zoom_sample_ptr = 0. */
+int t41o_channel_set_display(t41o_channel *ch, int spectrumZoom);
 
 #ifdef __cplusplus
 }

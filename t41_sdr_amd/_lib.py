@@ -66,6 +66,7 @@ SYMBOLS = {
     "t41rx_get_state": (C.c_int, [_vp, _vp, C.c_size_t]),
     "t41rx_set_state": (C.c_int, [_vp, _vp, C.c_size_t]),
     "t41rx_set_debug_taps": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int]),
+    "t41rx_set_display_spectrum": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int]),
 }
 
 _lib = None

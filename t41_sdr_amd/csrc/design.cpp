@@ -193,6 +193,21 @@ void agc_constants(const t41rx_params &p, float *out) {
 const float kDeemphFir24000[kDeemphTaps] = {
     0.000481913f, -0.000816211f, -0.00205384f, -0.00264474f, -0.00258229f, -0.00247939f, -0.00305299f, -0.00448116f, -0.00620366f, -0.00737591f, -0.00761292f, -0.00737176f, -0.0075984f, -0.00890065f, -0.0109592f, -0.0127338f, -0.0133493f, -0.0129165f, -0.0125289f, -0.013351f, -0.0155348f, -0.0179452f, -0.0190498f, -0.0183068f, -0.016827f, -0.0165808f, -0.0186455f, -0.0219659f, -0.0238965f, -0.0223995f, -0.0182146f, -0.0149414f, -0.0163342f, -0.0223751f, -0.0271497f, -0.020849f, 0.00446391f, 0.0485999f, 0.100768f, 0.143223f, 0.159583f, 0.143223f, 0.100768f, 0.0485999f, 0.00446391f, -0.020849f, -0.0271497f, -0.0223751f, -0.0163342f, -0.0149414f, -0.0182146f, -0.0223995f, -0.0238965f, -0.0219659f, -0.0186455f, -0.0165808f, -0.016827f, -0.0183068f, -0.0190498f, -0.0179452f, -0.0155348f, -0.013351f, -0.0125289f, -0.0129165f, -0.0133493f, -0.0127338f, -0.0109592f, -0.00890065f, -0.0075984f, -0.00737176f, -0.00761292f, -0.00737591f, -0.00620366f, -0.00448116f, -0.00305299f, -0.00247939f, -0.00258229f, -0.00264474f, -0.00205384f, -0.000816211f, 0.000481913f};
 
+// mag_coeffs[1..4] (FIR.cpp:582-680): the display zoom's 4-stage elliptic low-passes for 2x .. 16x
+// (MAX_ZOOM_ENTRIES = 5, ButtonProc.h:6), a fixed table of the reference
+const float kZoomIirCoeffs[4][20] = {
+    {0.228454526413293696f, 0.077639329099949764f, 0.228454526413293696f, 0.635534925142242080f, -0.170083307068779194f, 0.436788292542003964f, 0.232307972937606161f, 0.436788292542003964f, 0.365885230717786780f, -0.471769788739400842f, 0.535974654742658707f, 0.557035600464780845f, 0.535974654742658707f, 0.125740787233286133f, -0.754725697183384336f, 0.501116342273565607f, 0.914877831284765408f, 0.501116342273565607f, 0.013862536615004284f, -0.930973052446900984f},
+    {0.182208761527446556f, -0.222492493114674145f, 0.182208761527446556f, 1.326111070880959810f, -0.468036100821178802f, 0.337123762652097259f, -0.366352718812586853f, 0.337123762652097259f, 1.337053579516321200f, -0.644948386007929031f, 0.336163175380826074f, -0.199246162162897811f, 0.336163175380826074f, 1.354952684569386670f, -0.828032873168141115f, 0.178588201750411041f, 0.207271695028067304f, 0.178588201750411041f, 1.386486967455699220f, -0.950935065984588657f},
+    {0.185643392652478922f, -0.332064345389014803f, 0.185643392652478922f, 1.654637402827731090f, -0.693859842743674182f, 0.327519300813245984f, -0.571358085216950418f, 0.327519300813245984f, 1.715375037176782860f, -0.799055553586324407f, 0.283656142708241688f, -0.441088976843048652f, 0.283656142708241688f, 1.778230635987093860f, -0.904453944560528522f, 0.079685368654848945f, -0.011231810140649204f, 0.079685368654848945f, 1.825046003243238070f, -0.973184930412286708f},
+    {0.194769868656866380f, -0.379098413160710079f, 0.194769868656866380f, 1.824436402073870810f, -0.834877726226893380f, 0.333973874901496770f, -0.646106479315673776f, 0.333973874901496770f, 1.871892825636887640f, -0.893734096124207178f, 0.272903880596429671f, -0.513507745397738469f, 0.272903880596429671f, 1.918161772571113750f, -0.950461788366234739f, 0.053535383722369843f, -0.069683422367188122f, 0.053535383722369843f, 1.948900719896301760f, -0.986288064973853129f},
+};
+
+// ZoomFFTPrep(), FFT.cpp:38-39: CalcFIRCoeffs(Fir_Zoom_FFT_Decimate_coeffs, 4, 0.5 * SampleRate / 2^zoom, 60, 0, 0.0, SampleRate)
+void design_zoom_fir(int spectrumZoom, float (&coeffs)[4]) {
+  const float Fstop_Zoom = 0.5 * (float)kSampleRate / (1 << spectrumZoom);
+  kaiser_lowpass(coeffs, 4, Fstop_Zoom, 60, (float)kSampleRate);
+}
+
 bool params_valid(const t41rx_params &p, const char **why) {
   auto fail = [&](const char *m) {
     if (why) *why = m;

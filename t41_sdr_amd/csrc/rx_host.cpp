@@ -34,6 +34,11 @@ struct t41rx_ctx {
   float *dbg_nco = nullptr, *dbg_dec = nullptr, *dbg_demod = nullptr;
   float *spect = nullptr, *spect_max = nullptr;  // audio-spectrum side output (t41rx_set_audio_spectrum)
   int tap_frames = 0, spect_frames = 0;          // frames per call those buffers are sized for
+  // display FFT side output (t41rx_set_display_spectrum)
+  float *disp_spec = nullptr, *disp_old = nullptr;  // caller's buffers
+  float *d_pre = nullptr, *d_disp = nullptr;         // input tap [nchan][disp_frames][4096], state [nchan][kDispFloats]
+  double *d_win = nullptr;
+  int disp_frames = 0, disp_zoom = 0;
   // FFT_LENGTH 4096 pipeline: constant table + scratch between its three kernels
   float2 *d_tab4k = nullptr;
   float *d_mid = nullptr, *d_aud24 = nullptr;
@@ -215,6 +220,7 @@ int reset_state(t41rx_ctx *ctx) {
   }
   HIP_TRY(hipMemcpy(ctx->d_state, h.data(), sizeof(float) * h.size(), hipMemcpyHostToDevice));
   ctx->nco_sel = 0;
+  if (ctx->d_disp) HIP_TRY(hipMemset(ctx->d_disp, 0, sizeof(float) * kDispFloats * (size_t)ctx->nchan));
   return T41RX_OK;
 }
 
@@ -230,6 +236,9 @@ void free_ctx(t41rx_ctx *ctx) {
   (void)hipFree(ctx->d_in_i);
   (void)hipFree(ctx->d_in_q);
   (void)hipFree(ctx->d_out);
+  (void)hipFree(ctx->d_pre);
+  (void)hipFree(ctx->d_disp);
+  (void)hipFree(ctx->d_win);
   delete ctx;
 }
 
@@ -513,6 +522,10 @@ int process_device_impl(t41rx_ctx *ctx, const float *dI, const float *dQ, float 
     return fail(T41RX_ERR_ARG, "n_frames exceeds the max_frames the debug tap buffers were set with");
   if (ctx->spect && n_frames > ctx->spect_frames)
     return fail(T41RX_ERR_ARG, "n_frames exceeds the max_frames the audio-spectrum buffers were set with");
+  if (ctx->disp_spec && n_frames > ctx->disp_frames)
+    return fail(T41RX_ERR_ARG, "n_frames exceeds the max_frames the display-spectrum buffers were set with");
+  if (ctx->disp_spec && q15) return fail(T41RX_ERR_UNSUPPORTED, "the display spectrum is not available on the q15 entry points");
+  a.dbg_pre = ctx->disp_spec ? ctx->d_pre : nullptr;
   a.dbg_nco = ctx->dbg_nco;
   a.dbg_dec = ctx->dbg_dec;
   a.dbg_demod = ctx->dbg_demod;
@@ -521,6 +534,24 @@ int process_device_impl(t41rx_ctx *ctx, const float *dI, const float *dQ, float 
   hipError_t e = launch_rx(a, ctx->params.fft_length, ctx->params.mode, (hipStream_t)hip_stream);
   if (e != hipSuccess) return hip_fail(e, "kernel launch");
   if (seg > 1) ctx->nco_sel ^= 1;  // the kernels wrote the other copy
+  if (ctx->disp_spec) {
+    DispArgs d{};
+    d.pre = ctx->d_pre;
+    d.disp = ctx->d_disp;
+    d.spec = ctx->disp_spec;
+    d.spec_old = ctx->disp_old;
+    d.tab = ctx->d_tab;
+    d.win = ctx->d_win;
+    d.nchan = ctx->nchan;
+    d.nframes = n_frames;
+    d.zoom = ctx->disp_zoom;
+    if (d.zoom > 0) {
+      std::memcpy(d.iir, kZoomIirCoeffs[d.zoom - 1], sizeof(d.iir));
+      design_zoom_fir(d.zoom, d.fir);
+    }
+    e = launch_display(d, (hipStream_t)hip_stream);
+    if (e != hipSuccess) return hip_fail(e, "display kernel launch");
+  }
   return T41RX_OK;
 }
 
@@ -660,6 +691,40 @@ int t41rx_set_audio_spectrum(t41rx_ctx *ctx, float *d_spect, float *d_max, int m
   ctx->spect = d_spect;
   ctx->spect_max = d_max;
   ctx->spect_frames = d_spect ? max_frames : 0;
+  return T41RX_OK;
+}
+
+int t41rx_set_display_spectrum(t41rx_ctx *ctx, float *d_spec, float *d_spec_old, int spectrumZoom, int max_frames) {
+  if (!ctx) return fail(T41RX_ERR_ARG, "null context");
+  if ((d_spec == nullptr) != (d_spec_old == nullptr)) return fail(T41RX_ERR_ARG, "set both pointers or neither");
+  DeviceGuard g(ctx->device);
+  HIP_TRY(hipDeviceSynchronize());
+  if (!d_spec) {
+    ctx->disp_spec = ctx->disp_old = nullptr;
+    ctx->disp_frames = 0;
+    return T41RX_OK;
+  }
+  if (ctx->params.fft_length != 512) return fail(T41RX_ERR_UNSUPPORTED, "the display FFT is built for fft_length 512");
+  if (spectrumZoom < 0 || spectrumZoom > 4) return fail(T41RX_ERR_ARG, "spectrumZoom must be 0 (1x) .. 4 (16x)");  // MAX_ZOOM_ENTRIES, ButtonProc.h:6
+  if (max_frames <= 0) return fail(T41RX_ERR_ARG, "max_frames must be > 0");
+  if ((reinterpret_cast<uintptr_t>(d_spec) | reinterpret_cast<uintptr_t>(d_spec_old)) & 3u) return fail(T41RX_ERR_ARG, "unaligned pointer");
+  if (max_frames > ctx->disp_frames || !ctx->d_pre) {
+    (void)hipFree(ctx->d_pre);
+    ctx->d_pre = nullptr;
+    HIP_TRY(hipMalloc((void **)&ctx->d_pre, sizeof(float) * 4096 * (size_t)max_frames * (size_t)ctx->nchan));
+  }
+  if (!ctx->d_disp) HIP_TRY(hipMalloc((void **)&ctx->d_disp, sizeof(float) * kDispFloats * (size_t)ctx->nchan));
+  if (!ctx->d_win) {
+    HIP_TRY(hipMalloc((void **)&ctx->d_win, sizeof(double) * 512));
+    double w[512];
+    for (int i = 0; i < 512; ++i) w[i] = 0.5 - 0.5 * std::cos(6.28 * i / 512);  // FFT.cpp:110, 222 ("Hanning", 6.28 as written)
+    HIP_TRY(hipMemcpy(ctx->d_win, w, sizeof(w), hipMemcpyHostToDevice));
+  }
+  HIP_TRY(hipMemset(ctx->d_disp, 0, sizeof(float) * kDispFloats * (size_t)ctx->nchan));  // ZoomFFTPrep(): a fresh start
+  ctx->disp_spec = d_spec;
+  ctx->disp_old = d_spec_old;
+  ctx->disp_frames = max_frames;
+  ctx->disp_zoom = spectrumZoom;
   return T41RX_OK;
 }
 

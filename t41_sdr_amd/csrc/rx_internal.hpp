@@ -69,6 +69,18 @@ inline BlobView blob_view(void *blob) {
   return v;
 }
 
+// ---- display FFT side output (FFT.cpp:28-251) ----
+extern const float kZoomIirCoeffs[4][20];
+void design_zoom_fir(int spectrumZoom, float (&coeffs)[4]);
+// per-channel display state (floats): the zoom filters' memories, the 512-sample ring and its
+// pointer, FFT_spec_old
+constexpr int kDispIir = 0;       // [2][16]: IIR_biquad_Zoom_FFT_{I,Q}_state (x1, x2, y1, y2 per stage)
+constexpr int kDispFir = 32;      // [2][4]: the decimating FIR's last 3 inputs (+ pad)
+constexpr int kDispPtr = 40;      // zoom_sample_ptr (int32)
+constexpr int kDispRing = 64;     // [2][512]: FFT_ring_buffer_x / _y
+constexpr int kDispOld = 64 + 1024;  // [512]: FFT_spec_old
+constexpr int kDispFloats = kDispOld + 512;
+
 // host designer (design.cpp)
 int design_blob(const t41rx_params &p, void *blob, size_t blob_bytes);
 bool params_valid(const t41rx_params &p, const char **why);

@@ -38,6 +38,7 @@ struct RxArgs {
   float *dbg_nco;
   float *dbg_dec;
   float *dbg_demod;
+  float *dbg_pre;          // [nchan][nframes][2][2048]: I / Q after the IQ correction, before the Fs/4 shift (display FFT input)
   float *spect;            // audioSpectBuffer side output [nchan][nframes][1024] (or null)
   float *spect_max;        // [nchan][nframes][3]: audioMaxSquared, AudioMaxIndex, audioMaxSquaredAve
   // FFT_LENGTH 4096 pipeline scratch (device, owned by the context)
@@ -67,5 +68,19 @@ struct RxArgs {
 constexpr int tab_long_entries(int R) { return (R - 1) * 512 + R * 512; }
 
 hipError_t launch_rx(const RxArgs &a, int fft_length, int mode, hipStream_t s);
+
+// display FFT (CalcZoom1Magn / ZoomFFTExe, FFT.cpp:67-251) on the dbg_pre tap of the frames just processed
+struct DispArgs {
+  const float *pre;        // RxArgs::dbg_pre
+  float *disp;             // [nchan][kDispFloats] display state
+  float *spec;             // [nchan][nframes][512] FFT_spec
+  float *spec_old;         // [nchan][nframes][512] FFT_spec_old
+  const float2 *tab;       // the context's constant table (FFT twiddles)
+  const double *win;       // [512]: 0.5 - 0.5 cos(6.28 i / 512), as the reference's double expression
+  float iir[20];           // mag_coeffs[spectrumZoom] (unused for zoom 0)
+  float fir[4];            // Fir_Zoom_FFT_Decimate_coeffs
+  int nchan, nframes, zoom;
+};
+hipError_t launch_display(const DispArgs &a, hipStream_t s);
 
 }  // namespace t41

@@ -216,6 +216,15 @@ class RxChain:
         check(self._lib.t41rx_set_audio_spectrum(self._ctx, ps, pm, min(frames) if frames else 0))
         self._spect = (spect, maxima)  # keep alive
 
+    def set_display_spectrum(self, spec=None, spec_old=None, spectrumZoom=1):
+        """the display FFT (CalcZoom1Magn / ZoomFFTExe, FFT.cpp:67-251): torch CUDA float32 tensors
+        [n_channels, n_frames, 512] for FFT_spec and FFT_spec_old, or None/None to switch it off"""
+        ps, fs = self._side_tensor(spec, 512, "spec")
+        po, fo = self._side_tensor(spec_old, 512, "spec_old")
+        frames = [f for f in (fs, fo) if f is not None]
+        check(self._lib.t41rx_set_display_spectrum(self._ctx, ps, po, int(spectrumZoom), min(frames) if frames else 0))
+        self._disp = (spec, spec_old)  # keep alive
+
     def _check_out_torch(self, out, like):
         if not (out.is_cuda and out.dtype == like.dtype and out.is_contiguous() and tuple(out.shape) == tuple(like.shape)
                 and out.device == like.device):

@@ -13,7 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 
 DEMOD_USB, DEMOD_LSB, DEMOD_AM, DEMOD_NFM = 0, 1, 2, 3
-TAP_POST_NCO_I, TAP_POST_NCO_Q, TAP_DEC_I, TAP_DEC_Q, TAP_IFFT, TAP_DEMOD, TAP_AGC_VOLTS, TAP_AUDIO_SPECT, TAP_AUDIO_MAX, TAP_AGC_EDGES = range(10)
+(TAP_POST_NCO_I, TAP_POST_NCO_Q, TAP_DEC_I, TAP_DEC_Q, TAP_IFFT, TAP_DEMOD, TAP_AGC_VOLTS, TAP_AUDIO_SPECT, TAP_AUDIO_MAX,
+ TAP_AGC_EDGES, TAP_FFT_SPEC, TAP_FFT_SPEC_OLD) = range(12)
 AGC_NAMES = ("attack_mult", "decay_mult", "fast_decay_mult", "fast_backmult", "onemfast_backmult",
              "hang_backmult", "onemhang_backmult", "hang_decay_mult", "out_target", "min_volts",
              "slope_constant", "inv_max_input", "hang_level", "pop_ratio", "hang_count", "attack_buffsize")
@@ -101,6 +102,8 @@ def lib(native=False):
     L.t41o_process_batch_q15.restype = C.c_int
     L.t41o_channel_tap.argtypes = [C.c_void_p, C.c_int, fp, C.c_int]
     L.t41o_channel_tap.restype = C.c_int
+    L.t41o_channel_set_display.argtypes = [C.c_void_p, C.c_int]
+    L.t41o_channel_set_display.restype = C.c_int
     if not native:
         _lib = L
     return L
@@ -193,6 +196,13 @@ class OracleBatch:
         dst = np.zeros(n, dtype=np.float32)
         got = self.L.t41o_channel_tap(self.chs[ch], which, fptr(dst), n)
         return dst[:got]
+
+    def set_display(self, spectrumZoom):
+        """the display FFT side output (FFT.cpp:67-251): spectrumZoom 0..4, -1 = off; ZoomFFTPrep() semantics"""
+        for i in range(self.nchan):
+            rc = self.L.t41o_channel_set_display(self.chs[i], int(spectrumZoom))
+            if rc:
+                raise ValueError("t41o_channel_set_display rc=%d" % rc)
 
     def reset(self):
         for i in range(self.nchan):

@@ -164,6 +164,18 @@ int t41o_channel_tap(const t41o_channel *ch, int which, float *dst, int maxlen);
  * in every frame), -1 = off (the default).  Like ZoomFFTPrep(): zoom filters re-initialised, zoom_sample_ptr = 0. */
 int t41o_channel_set_display(t41o_channel *ch, int spectrumZoom);
 
+
+/* ---- transmit exciter, ExciterIQData() (Exciter.cpp:46-169): oracle/t41_tx_oracle.c ---- */
+typedef struct t41o_tx_channel t41o_tx_channel;
+t41o_tx_channel *t41o_tx_create(void);
+void t41o_tx_destroy(t41o_tx_channel *ch);
+void t41o_tx_reset(t41o_tx_channel *ch);
+/* one frame: 2048 q15 samples per input queue in, 2048 per output queue out; mode = T41O_DEMOD_* */
+int t41o_tx_process_frame(t41o_tx_channel *ch, int mode, float IQXAmpCorrectionFactor, float IQXPhaseCorrectionFactor,
+                          const int16_t *Q_in_L_Ex, const int16_t *Q_in_R_Ex, int16_t *Q_out_L_Ex, int16_t *Q_out_R_Ex);
+/* the fixed tables FIR.cpp:177-276, 373-579: 0 coeffs192K_10K_LPF_FIR, 1 coeffs48K_8K_LPF_FIR, 2 / 3 FIR_Hilbert_coeffs_45 / _neg45 */
+const float *t41o_tx_table(int which, int *n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,6 +7,7 @@ creating an RxChain does.
 from ._lib import (DEMOD_AM, DEMOD_LSB, DEMOD_NFM, DEMOD_USB, LIB_PATH, Params, T41RxError,  # noqa: F401
                    load)
 from .rx import RxChain, blob_fields, blob_params, default_params, design_coeffs  # noqa: F401
+from .tx import TxChain, TxParams, default_tx_params  # noqa: F401
 
 __all__ = ["RxChain", "Params", "T41RxError", "default_params", "design_coeffs", "blob_fields", "load",
            "DEMOD_USB", "DEMOD_LSB", "DEMOD_AM", "DEMOD_NFM", "LIB_PATH"]

@@ -104,6 +104,13 @@ def lib(native=False):
     L.t41o_channel_tap.restype = C.c_int
     L.t41o_channel_set_display.argtypes = [C.c_void_p, C.c_int]
     L.t41o_channel_set_display.restype = C.c_int
+    L.t41o_tx_create.restype = C.c_void_p
+    L.t41o_tx_destroy.argtypes = [C.c_void_p]
+    L.t41o_tx_reset.argtypes = [C.c_void_p]
+    L.t41o_tx_process_frame.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, sp, sp, sp, sp]
+    L.t41o_tx_process_frame.restype = C.c_int
+    L.t41o_tx_table.argtypes = [C.c_int, C.POINTER(C.c_int)]
+    L.t41o_tx_table.restype = fp
     if not native:
         _lib = L
     return L
@@ -213,6 +220,48 @@ class OracleBatch:
             if self.chs[i]:
                 self.L.t41o_channel_destroy(self.chs[i])
                 self.chs[i] = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class TxOracleBatch:
+    """nchan independent oracle exciters (oracle/t41_tx_oracle.c) run through consecutive frames"""
+
+    def __init__(self, nchan, mode=DEMOD_USB, amp=1.0, phase=0.0):
+        self.L = lib()
+        self.nchan, self.mode, self.amp, self.phase = nchan, mode, amp, phase
+        self.chs = [self.L.t41o_tx_create() for _ in range(nchan)]
+
+    def process(self, Q_in_L_Ex, Q_in_R_Ex=None):
+        a = np.ascontiguousarray(Q_in_L_Ex, dtype=np.int16)
+        b = a if Q_in_R_Ex is None else np.ascontiguousarray(Q_in_R_Ex, dtype=np.int16)
+        assert a.shape[0] == self.nchan and a.shape[1] % 2048 == 0
+        oL, oR = np.empty_like(a), np.empty_like(a)
+        sp = C.POINTER(C.c_int16)
+        for c in range(self.nchan):
+            for f in range(a.shape[1] // 2048):
+                sl = slice(f * 2048, (f + 1) * 2048)
+                ia, ib = np.ascontiguousarray(a[c, sl]), np.ascontiguousarray(b[c, sl])
+                ol, orr = np.empty(2048, np.int16), np.empty(2048, np.int16)
+                rc = self.L.t41o_tx_process_frame(self.chs[c], self.mode, self.amp, self.phase, ia.ctypes.data_as(sp),
+                                                  ib.ctypes.data_as(sp), ol.ctypes.data_as(sp), orr.ctypes.data_as(sp))
+                assert rc == 0
+                oL[c, sl], oR[c, sl] = ol, orr
+        return oL, oR
+
+    def table(self, which):
+        n = C.c_int()
+        p = self.L.t41o_tx_table(which, C.byref(n))
+        return np.ctypeslib.as_array(p, shape=(n.value,)).copy()
+
+    def close(self):
+        for c in self.chs:
+            self.L.t41o_tx_destroy(c)
+        self.chs = []
 
     def __del__(self):
         try:

@@ -2298,7 +2298,7 @@ __global__ __launch_bounds__((Geo<PART, AGC>::kWaves * 64), 4) void rx512_kernel
 // 36 KiB per workgroup at R = 8, four workgroups (16 waves) per CU.
 constexpr int kFcRow = 8 * kFftRow;  // complex units per padded row
 static_assert(kFcRow >= 512, "row padding");
-constexpr int fc_lds_floats(int R) { return 2 * kFcRow * R; }
+constexpr int fc_lds_floats(int R) { return 2 * kFcRow * R + 2 * (448 + 56); }  // working array + the 512-point FFT's twiddles
 
 template <int R, bool INV>
 __device__ __forceinline__ void dft_r(cf (&v)[R]) {
@@ -2322,8 +2322,11 @@ __device__ __forceinline__ void dft_r(cf (&v)[R]) {
 // N = 512 R, R = 2, 4, 8 (FFT_LENGTH 1024, 2048, 4096).  CPLX: hand the complex valid half on as it
 // is (AM, AGC on: the back kernel applies the AGC / gain and demodulates), else the SSB audio
 // fixed_gain * Re.
+#ifndef T41RX_FC_WAVES
+#define T41RX_FC_WAVES 3  // waves per SIMD the register allocation is held to (R = 8 needs ~148 VGPRs: 3 workgroups per CU; measured equal to 4 with spills)
+#endif
 template <int R, bool CPLX>
-__global__ __launch_bounds__(256) void fastconv_kernel(const RxArgs a) {
+__global__ __launch_bounds__(256, T41RX_FC_WAVES) void fastconv_kernel(const RxArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int N = 512 * R, D = N / 2;
   const int lane = threadIdx.x & 63;
@@ -2331,18 +2334,24 @@ __global__ __launch_bounds__(256) void fastconv_kernel(const RxArgs a) {
   const int ch = blockIdx.x;
   if (ch >= a.nchan) return;
   cf *A = reinterpret_cast<cf *>(smem);
+  // behind the working array: the 512-point FFT's twiddles (tw1 [7][64], tw2 compacted to [7][8]),
+  // read at the point of use -- the registers they would occupy hold what must not wait for L2
+  cf *ltw = A + kFcRow * R;
   float *st = a.state + (size_t)ch * state_floats(N);
   const cf *twN = reinterpret_cast<const cf *>(a.tab4k);                    // [R-1][512]
   const cf *maskN = reinterpret_cast<const cf *>(a.tab4k) + (R - 1) * 512;  // [R][512]
   const cf *tab = reinterpret_cast<const cf *>(a.tab);
   const float fixed_gain = ((CoefPtr)a.coef)->sc[kScFixedGain];
 
-  cf tw1[7], tw2[7];
+  for (int i = threadIdx.x; i < 448; i += 256) ltw[i] = tab[kTabTw1 + i];
+  if (threadIdx.x < 56) ltw[448 + threadIdx.x] = tab[kTabTw2 + 64 * (threadIdx.x >> 3) + (threadIdx.x & 7)];
+  // the outer radix-R pass' twiddles of this wave's two column blocks (r = wv, wv + 4) stay in
+  // registers for the whole call: passes 1 and 3 of every frame use the same ones
+  cf twp[2][R > 1 ? R - 1 : 1];
 #pragma unroll
-  for (int q = 0; q < 7; ++q) {
-    tw1[q] = tab[kTabTw1 + 64 * q + lane];
-    tw2[q] = tab[kTabTw2 + 64 * q + lane];
-  }
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int q = 1; q < R; ++q) twp[h][q - 1] = twN[512 * (q - 1) + lane + 64 * (wv + 4 * h)];
 
   for (int f = 0; f < a.nframes4k; ++f) {
     // ---- overlap-save assemble (Process.cpp:498-522): [previous N/2 | new N/2].  Inside a call the
@@ -2351,7 +2360,7 @@ __global__ __launch_bounds__(256) void fastconv_kernel(const RxArgs a) {
     const float4 *mid = reinterpret_cast<const float4 *>(a.mid + ((size_t)ch * a.nframes4k + f) * (2 * D));
     const float4 *prev = (f == 0) ? reinterpret_cast<const float4 *>(st + kStOverlap) : mid - N / 4;
     float4 *A4 = reinterpret_cast<float4 *>(smem);
-    __syncthreads();  // the previous frame's pass 3 is done with the array
+    __syncthreads();  // the previous frame's pass 3 is done with the array (first frame: the twiddles are staged)
 #pragma unroll
     for (int i = wv; i < N / 256; i += 4) {  // float4 = 2 complex; 256 float4 per row
       const float4 p = prev[64 * i + lane];
@@ -2362,48 +2371,62 @@ __global__ __launch_bounds__(256) void fastconv_kernel(const RxArgs a) {
       A4[rn * (kFcRow / 2) + ((e + N / 4) & 255)] = n;
       if (f == a.nframes4k - 1) reinterpret_cast<float4 *>(st + kStOverlap)[64 * i + lane] = n;  // next call's "previous"
     }
+    // the filter mask of this wave's rows of pass 2 (q = wv, wv + 4): requested now, used two
+    // barriers later, so its L2 round trip runs under pass 1
+    cf mk[2][8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int q = wv + 4 * h;
+      if (q < R) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) mk[h][r] = maskN[512 * q + lane + 64 * r];
+      }
+    }
     __syncthreads();
     // ---- pass 1
-#pragma unroll 1
-    for (int r = wv; r < 8; r += 4) {
-      const int k = lane + 64 * r;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int k = lane + 64 * (wv + 4 * h);
       cf v[R];
 #pragma unroll
       for (int p = 0; p < R; ++p) v[p] = A[k + kFcRow * p];
       dft_r<R, false>(v);
 #pragma unroll
-      for (int q = 1; q < R; ++q) v[q] = cmul(v[q], twN[512 * (q - 1) + k]);
+      for (int q = 1; q < R; ++q) v[q] = cmul(v[q], twp[h][q - 1]);
 #pragma unroll
       for (int q = 0; q < R; ++q) A[k + kFcRow * q] = v[q];
     }
     __syncthreads();
     // ---- pass 2: 512-point FFT, mask (pre-scaled by 1/N), inverse 512-point FFT, per q
-#pragma unroll 1
-    for (int q = wv; q < R; q += 4) {
-      cf v[8];
 #pragma unroll
-      for (int r = 0; r < 8; ++r) v[r] = A[kFcRow * q + lane + 64 * r];
-      float *xbuf = smem + 2 * kFcRow * q;  // the row itself (now in registers) is the exchange scratch
-      wave_sync();
-      fft512<false>(v, tw1, tw2, xbuf, lane);
+    for (int h = 0; h < 2; ++h) {
+      const int q = wv + 4 * h;
+      if (q < R) {
+        cf v[8];
 #pragma unroll
-      for (int r = 0; r < 8; ++r) v[r] = cmul(v[r], maskN[512 * q + lane + 64 * r]);
-      fft512<true>(v, tw1, tw2, xbuf, lane);
-      wave_sync();
+        for (int r = 0; r < 8; ++r) v[r] = A[kFcRow * q + lane + 64 * r];
+        float *xbuf = smem + 2 * kFcRow * q;  // the row itself (now in registers) is the exchange scratch
+        wave_sync();
+        fft512_ldstw<false>(v, ltw + lane, ltw + 448 + (lane & 7), xbuf, lane, []() {});
 #pragma unroll
-      for (int r = 0; r < 8; ++r) A[kFcRow * q + lane + 64 * r] = v[r];
+        for (int r = 0; r < 8; ++r) v[r] = cmul(v[r], mk[h][r]);
+        fft512_ldstw<true>(v, ltw + lane, ltw + 448 + (lane & 7), xbuf, lane, []() {});
+        wave_sync();
+#pragma unroll
+        for (int r = 0; r < 8; ++r) A[kFcRow * q + lane + 64 * r] = v[r];
+      }
     }
     __syncthreads();
     // ---- pass 3; AGC off: fixed gain (DSP_Fn.cpp:494-502); SSB: audio = Re of the valid half
     float *au = a.aud24 + ((size_t)ch * a.nframes4k + f) * D;
-#pragma unroll 1
-    for (int r = wv; r < 8; r += 4) {
-      const int k = lane + 64 * r;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int k = lane + 64 * (wv + 4 * h);
       cf v[R];
 #pragma unroll
       for (int q = 0; q < R; ++q) v[q] = A[k + kFcRow * q];
 #pragma unroll
-      for (int q = 1; q < R; ++q) v[q] = cmulc(v[q], twN[512 * (q - 1) + k]);
+      for (int q = 1; q < R; ++q) v[q] = cmulc(v[q], twp[h][q - 1]);
       dft_r<R, true>(v);
 #pragma unroll
       for (int p = R / 2; p < R; ++p) {

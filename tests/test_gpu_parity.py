@@ -684,6 +684,39 @@ def test_full_batch_nfm(T):
     assert siggen.block_rel_err(out[torch.from_numpy(idx).cuda()].cpu().numpy(), ref, L).max() <= TOL
 
 
+@pytest.mark.parametrize("fft_length", [1024, 4096])
+def test_segment_run_length_invariance(T, fft_length, monkeypatch):
+    """The long-FFT front / back kernels run segments in parallel and rebuild the filter memories of a
+    wave that starts inside the call from the preceding input: the audio and the
+    channel state must not depend on how many segments one wave runs."""
+    import torch
+    nch, nfr = 64, 6
+    Lf = fft_length * 4
+    rng = np.random.default_rng(fft_length)
+    nco = (rng.integers(-860, 801, nch) * 50).astype(np.int32)
+    kw = dict(fft_length=fft_length, mode=0, FLoCut=400, FHiCut=600)
+    g = torch.Generator(device="cuda").manual_seed(fft_length + 1)
+    x = 0.2 * torch.randn(nch, nfr * Lf, generator=g, device="cuda")
+    y = 0.2 * torch.randn(nch, nfr * Lf, generator=g, device="cuda")
+    outs, states = [], []
+    for run in ("1", "3", "8", None):
+        if run is None:
+            monkeypatch.delenv("T41RX_SEG_RUN", raising=False)
+        else:
+            monkeypatch.setenv("T41RX_SEG_RUN", run)
+        rx = T.RxChain(nch, T.default_params(**kw), NCOFreq=nco)
+        a = rx.ProcessIQData(x[:, :4 * Lf].contiguous(), y[:, :4 * Lf].contiguous())
+        b = rx.ProcessIQData(x[:, 4 * Lf:].contiguous(), y[:, 4 * Lf:].contiguous())
+        outs.append(torch.cat([a, b], dim=1))
+        states.append(rx.get_state())
+    monkeypatch.delenv("T41RX_SEG_RUN", raising=False)
+    for o, s in zip(outs[1:], states[1:]):
+        assert torch.equal(o, outs[0])
+        assert np.array_equal(np.asarray(s), np.asarray(states[0]))
+    ref = oracle_run(kw, nco[:8], x[:8].cpu().numpy(), y[:8].cpu().numpy())
+    assert siggen.block_rel_err(outs[0][:8].cpu().numpy(), ref, Lf).max() <= TOL
+
+
 def test_full_batch_fft4096(T):
     """config 4: the 4096-point fast convolution at 1024 channels x 16384 samples: finite,
     channel-independent, frame-split invariant, and a 32-channel sample agrees with the oracle"""

@@ -673,7 +673,9 @@ int t41rx_set_state(t41rx_ctx *ctx, const void *host_buf, size_t bytes) {
 int t41rx_set_debug_taps(t41rx_ctx *ctx, float *d_post_nco, float *d_dec, float *d_demod, int max_frames) {
   if (!ctx) return fail(T41RX_ERR_ARG, "null argument");
   const bool any = d_post_nco || d_dec || d_demod;
-  if (any && ctx->params.fft_length != 512) return fail(T41RX_ERR_UNSUPPORTED, "the stage taps are built for fft_length 512");
+  // (T41RX_STAMP_TAPS: the -DT41RX_STAMP diagnostic kernels of the long-FFT pipeline put their cycle stamps behind the demod tap)
+  if (any && ctx->params.fft_length != 512 && !std::getenv("T41RX_STAMP_TAPS"))
+    return fail(T41RX_ERR_UNSUPPORTED, "the stage taps are built for fft_length 512");
   if (any && max_frames <= 0) return fail(T41RX_ERR_ARG, "max_frames must be > 0");
   ctx->dbg_nco = d_post_nco;
   ctx->dbg_dec = d_dec;

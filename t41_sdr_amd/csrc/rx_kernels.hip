@@ -236,7 +236,7 @@ __device__ __forceinline__ void fft512(cf (&v)[8], const cf (&tw1)[7], const cf 
 // held in 28 registers across both transforms: the fused kernel carries the next frame's input
 // prefetch through its back end and has no registers to spare.  `mid()` runs between the first and
 // the second stage (the fused kernel requests the filter mask there).
-template <bool INV, typename MID>
+template <bool INV, int TW2S = 8, typename MID>  // TW2S: stride of the second twiddle set (8 = compacted [7][8], 64 = read out of tw1)
 __device__ __forceinline__ void fft512_ldstw(cf (&v)[8], const cf *tw1l, const cf *tw2l, float *__restrict__ xbuf,
                                              int lane, MID mid) {
   cf *xb = reinterpret_cast<cf *>(xbuf);
@@ -259,7 +259,7 @@ __device__ __forceinline__ void fft512_ldstw(cf (&v)[8], const cf *tw1l, const c
   dft8<INV>(v);
 #pragma unroll
   for (int q = 1; q < 8; ++q) {
-    const cf w = tw2l[8 * (q - 1)];
+    const cf w = tw2l[TW2S * (q - 1)];
     v[q] = INV ? cmulc(v[q], w) : cmul(v[q], w);
   }
   wave_sync();
@@ -2300,6 +2300,19 @@ constexpr int kFcRow = 8 * kFftRow;  // complex units per padded row
 static_assert(kFcRow >= 512, "row padding");
 constexpr int fc_lds_floats(int R) { return 2 * kFcRow * R + 2 * (448 + 56); }  // working array + the 512-point FFT's twiddles
 
+// Waves per channel and LDS budget.  The kernel is bound by the latency of its barrier-separated
+// phases, not by any throughput (stamps: a workgroup alone on a CU is hardly faster than one of
+// three, and 8 waves per channel bought 3 %), so what counts is how many channels a CU holds at
+// once -- and that every channel of the 1024-channel batch is resident in ONE round (3 per CU =
+// 768 slots left a second round at a third of the occupancy: 16 frame-times where 10.7 would do).
+// Fused kernel, R = 8: four workgroups per CU = 40 KiB each = [working array 36 KiB | tw1 3.5 KiB |
+// interpolator histories]; the frame's audio and then the output transposition buffers alias the
+// working array (one more barrier), the second twiddle set is read out of the first
+// (W64^(q l1) = W512^(8 q l1), the same doubles rounded: identical values).
+constexpr int kFcWaves = 4;
+constexpr int fc_arr_floats(int R) { return 2 * kFcRow * R < kFcWaves * 2048 ? kFcWaves * 2048 : 2 * kFcRow * R; }  // >= the four transposition buffers
+constexpr int fcb_lds_floats(int R) { return fc_arr_floats(R) + 2 * 448 + 32 + 8 * (R + 1); }
+static_assert(fcb_lds_floats(8) * 4 * 4 <= 160 * 1024, "four fused workgroups per CU");
 template <int R, bool INV>
 __device__ __forceinline__ void dft_r(cf (&v)[R]) {
   if constexpr (R == 8) {
@@ -2323,46 +2336,74 @@ __device__ __forceinline__ void dft_r(cf (&v)[R]) {
 // is (AM, AGC on: the back kernel applies the AGC / gain and demodulates), else the SSB audio
 // fixed_gain * Re.
 #ifndef T41RX_FC_WAVES
-#define T41RX_FC_WAVES 3  // waves per SIMD the register allocation is held to (R = 8 needs ~148 VGPRs: 3 workgroups per CU; measured equal to 4 with spills)
+#define T41RX_FC_WAVES 4  // waves per SIMD the register allocation is held to (four workgroups per CU)
 #endif
-template <int R, bool CPLX>
-__global__ __launch_bounds__(256, T41RX_FC_WAVES) void fastconv_kernel(const RxArgs a) {
+// BACK: SSB / NFM audio with the fixed gain goes straight on through the x2 / x4 interpolators and
+// out (Process.cpp:917-931) instead of to the `aud24` scratch and a third kernel: pass 3 leaves
+// the frame's N/2 audio samples in LDS (where the working array was), then every wave runs whole
+// 256-sample segments of the back end (s = wave, wave + 4) with the arithmetic of rx512_kernel's,
+// the x4 interpolator's 7-sample history crossing the segment boundaries through LDS.
+template <int R, bool CPLX, bool BACK = false>
+__global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_kernel(const RxArgs a) {
+  static_assert(!(BACK && CPLX), "the fused back end takes real audio");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int N = 512 * R, D = N / 2;
-  const int lane = threadIdx.x & 63;
+  constexpr int NWV = kFcWaves, NT = 64 * NWV;  // waves / threads per channel
+  constexpr int H = 8 / NWV;                       // column blocks (passes 1, 3) / rows (pass 2) / segments (back end) per wave
+  int lane = threadIdx.x & 63;  // (re-defined per phase, see FRESH_LANE)
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ch = blockIdx.x;
   if (ch >= a.nchan) return;
   cf *A = reinterpret_cast<cf *>(smem);
-  // behind the working array: the 512-point FFT's twiddles (tw1 [7][64], tw2 compacted to [7][8]),
-  // read at the point of use -- the registers they would occupy hold what must not wait for L2
-  cf *ltw = A + kFcRow * R;
+  // behind the working array: the 512-point FFT's twiddles (tw1 [7][64]; BACK: tw2[q][l1] is
+  // tw1[q][8 l1], else compacted to [7][8] behind it), read at the point of use -- the registers
+  // they would occupy hold what must not wait for L2
+  constexpr int kArr = BACK ? fc_arr_floats(R) : 2 * kFcRow * R;
+  cf *ltw = reinterpret_cast<cf *>(smem + kArr);
+  const cf *ltw2 = BACK ? ltw + 8 * (lane & 7) : ltw + 448 + (lane & 7);
+  constexpr int kTw2Stride = BACK ? 64 : 8;
+  float *AU = smem;                       // BACK, from pass 3 to the x2 interpolator: [0] pad, [1..23] history, [24 + i] audio sample i of the frame
+  float *HI = smem + kArr + 2 * 448;      // BACK: the frame's last 24 audio samples, [0] pad (= AU[0..23] of the next frame)
+  float *YT = HI + 32;                    // BACK: [s][0] pad, [s][1..7] = the last 7 x2 outputs before segment s
+  static_assert(!BACK || 24 + D + 8 <= kArr, "the audio fits where the working array was");
   float *st = a.state + (size_t)ch * state_floats(N);
   const cf *twN = reinterpret_cast<const cf *>(a.tab4k);                    // [R-1][512]
   const cf *maskN = reinterpret_cast<const cf *>(a.tab4k) + (R - 1) * 512;  // [R][512]
   const cf *tab = reinterpret_cast<const cf *>(a.tab);
   const float fixed_gain = ((CoefPtr)a.coef)->sc[kScFixedGain];
 
-  for (int i = threadIdx.x; i < 448; i += 256) ltw[i] = tab[kTabTw1 + i];
-  if (threadIdx.x < 56) ltw[448 + threadIdx.x] = tab[kTabTw2 + 64 * (threadIdx.x >> 3) + (threadIdx.x & 7)];
+  for (int i = threadIdx.x; i < 448; i += NT) ltw[i] = tab[kTabTw1 + i];
+  if (!BACK && threadIdx.x < 56) ltw[448 + threadIdx.x] = tab[kTabTw2 + 64 * (threadIdx.x >> 3) + (threadIdx.x & 7)];
+  if (BACK) {  // interpolator memories of the channel
+    if (threadIdx.x < 24) HI[threadIdx.x] = st[kStInt1 + threadIdx.x];
+    else if (threadIdx.x >= 64 && threadIdx.x < 72) YT[threadIdx.x - 64] = st[kStInt2 + threadIdx.x - 64];
+  }
   // the outer radix-R pass' twiddles of this wave's two column blocks (r = wv, wv + 4) stay in
   // registers for the whole call: passes 1 and 3 of every frame use the same ones
-  cf twp[2][R > 1 ? R - 1 : 1];
+  cf twp[H][R > 1 ? R - 1 : 1];
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
+  for (int h = 0; h < H; ++h)
 #pragma unroll
-    for (int q = 1; q < R; ++q) twp[h][q - 1] = twN[512 * (q - 1) + lane + 64 * (wv + 4 * h)];
+    for (int q = 1; q < R; ++q) twp[h][q - 1] = twN[512 * (q - 1) + lane + 64 * (wv + NWV * h)];
 
+#ifdef T41RX_STAMP
+  unsigned long long stamp_acc = 0, stamp_last, stamp_t0;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_t0)::"memory");
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
+#endif
   for (int f = 0; f < a.nframes4k; ++f) {
+    FRESH_LANE();
     // ---- overlap-save assemble (Process.cpp:498-522): [previous N/2 | new N/2].  Inside a call the
     // previous block is the preceding frame's `mid` (just read, L2-warm); the state record supplies
     // it for the call's first frame and receives the last frame's block.
     const float4 *mid = reinterpret_cast<const float4 *>(a.mid + ((size_t)ch * a.nframes4k + f) * (2 * D));
     const float4 *prev = (f == 0) ? reinterpret_cast<const float4 *>(st + kStOverlap) : mid - N / 4;
     float4 *A4 = reinterpret_cast<float4 *>(smem);
+    STAMP(0);         // (tail of the previous frame: stores issued, history rolled)
     __syncthreads();  // the previous frame's pass 3 is done with the array (first frame: the twiddles are staged)
+    STAMP(1);
 #pragma unroll
-    for (int i = wv; i < N / 256; i += 4) {  // float4 = 2 complex; 256 float4 per row
+    for (int i = wv; i < N / 256; i += NWV) {  // float4 = 2 complex; 256 float4 per row
       const float4 p = prev[64 * i + lane];
       const float4 n = mid[64 * i + lane];
       const int e = 64 * i + lane;          // float4 index within a half (N/4 of them)
@@ -2373,20 +2414,24 @@ __global__ __launch_bounds__(256, T41RX_FC_WAVES) void fastconv_kernel(const RxA
     }
     // the filter mask of this wave's rows of pass 2 (q = wv, wv + 4): requested now, used two
     // barriers later, so its L2 round trip runs under pass 1
-    cf mk[2][8];
+    STAMP(2);  // assemble: global loads -> LDS
+    cf mk[H][8];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int q = wv + 4 * h;
+    for (int h = 0; h < H; ++h) {
+      const int q = wv + NWV * h;
       if (q < R) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) mk[h][r] = maskN[512 * q + lane + 64 * r];
       }
     }
+    STAMP(3);
     __syncthreads();
+    STAMP(4);
+    FRESH_LANE();
     // ---- pass 1
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int k = lane + 64 * (wv + 4 * h);
+    for (int h = 0; h < H; ++h) {
+      const int k = lane + 64 * (wv + NWV * h);
       cf v[R];
 #pragma unroll
       for (int p = 0; p < R; ++p) v[p] = A[k + kFcRow * p];
@@ -2396,32 +2441,39 @@ __global__ __launch_bounds__(256, T41RX_FC_WAVES) void fastconv_kernel(const RxA
 #pragma unroll
       for (int q = 0; q < R; ++q) A[k + kFcRow * q] = v[q];
     }
+    STAMP(5);
     __syncthreads();
+    STAMP(6);
+    FRESH_LANE();
     // ---- pass 2: 512-point FFT, mask (pre-scaled by 1/N), inverse 512-point FFT, per q
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int q = wv + 4 * h;
+    for (int h = 0; h < H; ++h) {
+      const int q = wv + NWV * h;
       if (q < R) {
         cf v[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] = A[kFcRow * q + lane + 64 * r];
         float *xbuf = smem + 2 * kFcRow * q;  // the row itself (now in registers) is the exchange scratch
         wave_sync();
-        fft512_ldstw<false>(v, ltw + lane, ltw + 448 + (lane & 7), xbuf, lane, []() {});
+        fft512_ldstw<false, kTw2Stride>(v, ltw + lane, ltw2, xbuf, lane, []() {});
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] = cmul(v[r], mk[h][r]);
-        fft512_ldstw<true>(v, ltw + lane, ltw + 448 + (lane & 7), xbuf, lane, []() {});
+        fft512_ldstw<true, kTw2Stride>(v, ltw + lane, ltw2, xbuf, lane, []() {});
         wave_sync();
 #pragma unroll
         for (int r = 0; r < 8; ++r) A[kFcRow * q + lane + 64 * r] = v[r];
       }
     }
+    STAMP(7);
     __syncthreads();
+    STAMP(8);
+    FRESH_LANE();
     // ---- pass 3; AGC off: fixed gain (DSP_Fn.cpp:494-502); SSB: audio = Re of the valid half
     float *au = a.aud24 + ((size_t)ch * a.nframes4k + f) * D;
+    float y3[H][R / 2];  // BACK: the audio samples k + 512 j of this wave's column blocks
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int k = lane + 64 * (wv + 4 * h);
+    for (int h = 0; h < H; ++h) {
+      const int k = lane + 64 * (wv + NWV * h);
       cf v[R];
 #pragma unroll
       for (int q = 0; q < R; ++q) v[q] = A[k + kFcRow * q];
@@ -2432,11 +2484,134 @@ __global__ __launch_bounds__(256, T41RX_FC_WAVES) void fastconv_kernel(const RxA
       for (int p = R / 2; p < R; ++p) {
         if (CPLX)
           reinterpret_cast<cf *>(a.aud24)[((size_t)ch * a.nframes4k + f) * D + k + 512 * (p - R / 2)] = v[p];
+        else if (BACK)
+          y3[h][p - R / 2] = fixed_gain * v[p].x;
         else
           au[k + 512 * (p - R / 2)] = fixed_gain * v[p].x;
       }
     }
+    if (BACK) {
+      const CoefPtr cf0 = (CoefPtr)a.coef;
+      float ci[48];  // the x2 interpolator's taps: requested here, so the scalar loads' latency runs under the barrier
+      load_taps<48>(ci, (CFloatPtr)fresh_coef(cf0)->int1);
+      STAMP(9);
+      __syncthreads();  // every wave has read its columns: the working array is free
+      FRESH_LANE();
+#pragma unroll
+      for (int h = 0; h < H; ++h)
+#pragma unroll
+        for (int j = 0; j < R / 2; ++j) AU[24 + lane + 64 * (wv + NWV * h) + 512 * j] = y3[h][j];
+      if (threadIdx.x < 24) AU[threadIdx.x] = HI[threadIdx.x];
+      __syncthreads();  // the frame's audio is complete
+      STAMP(10);
+      FRESH_LANE();
+      if (threadIdx.x < 24) HI[threadIdx.x] = AU[D + threadIdx.x];  // the next frame's history, before the transposition takes the place
+      // ---- interpolate by 2 (48 taps, phase length 24), segment s: inputs n = 4 lane .. 4 lane + 3
+      f2 u1[H][4];  // outputs (2n, 2n+1) of input n = 4 lane + u
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        const int sg = wv + NWV * h;
+        if (sg < R) {
+          const float *ib = AU + 256 * sg;
+          float w[28];
+#pragma unroll
+          for (int i = 0; i < 7; ++i) {
+            const float4 t = lds4(ib + 4 * lane + 4 * i);
+            w[4 * i] = t.x;
+            w[4 * i + 1] = t.y;
+            w[4 * i + 2] = t.z;
+            w[4 * i + 3] = t.w;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) u1[h][u] = splat(0.0f);
+#pragma unroll
+          for (int b = 0; b < 24; b += 8) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+              for (int t = 0; t < 8; ++t) u1[h][u] = pk_fma(splat(w[u + b + t + 1]), f2{ci[2 * b + 1 + 2 * t], ci[2 * b + 2 * t]}, u1[h][u]);
+            }
+          }
+          if (lane == 63) {  // what the next segment's x4 interpolator remembers
+            *reinterpret_cast<float4 *>(YT + 8 * (sg + 1)) = make_float4(0.0f, u1[h][0].y, u1[h][1].x, u1[h][1].y);
+            *reinterpret_cast<float4 *>(YT + 8 * (sg + 1) + 4) = make_float4(u1[h][2].x, u1[h][2].y, u1[h][3].x, u1[h][3].y);
+          }
+        }
+      }
+      float c4[32];  // the x4 interpolator's taps, likewise
+      load_taps<32>(c4, (CFloatPtr)fresh_coef(cf0)->int2);
+      const float out_scale = fresh_coef(cf0)->sc[kScOutScale];
+      STAMP(11);
+      __syncthreads();
+      STAMP(12);
+      FRESH_LANE();
+      if (f == a.nframes4k - 1) {  // the channel's interpolator memories after the call
+        if (threadIdx.x < 24) st[kStInt1 + threadIdx.x] = HI[threadIdx.x];
+        else if (threadIdx.x >= 64 && threadIdx.x < 72) st[kStInt2 + threadIdx.x - 64] = YT[8 * R + threadIdx.x - 64];
+      }
+      // ---- interpolate by 4 (32 taps, phase length 8): inputs n = 8 lane .. 8 lane + 7; volume;
+      // LDS transposition (2048 floats of the idle working array per wave); 1-KiB stores
+      float *gOf = a.out + ((size_t)ch * a.nframes4k + f) * (size_t)(8 * D);
+      float *tr = smem + 2048 * wv;
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        const int sg = wv + NWV * h;
+        if (sg < R) {
+          float w[15];
+          const float x1[8] = {u1[h][0].x, u1[h][0].y, u1[h][1].x, u1[h][1].y, u1[h][2].x, u1[h][2].y, u1[h][3].x, u1[h][3].y};
+#pragma unroll
+          for (int i = 0; i < 7; ++i) {
+            const float up = lane_up1(x1[i + 1]);
+            const float hs = YT[8 * sg + i + 1];
+            w[i] = (lane == 0) ? hs : up;
+          }
+#pragma unroll
+          for (int i = 0; i < 8; ++i) w[7 + i] = x1[i];
+          wave_sync();  // the buffer's previous readers are done
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            f2 o01 = splat(0.0f), o23 = splat(0.0f);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+              const f2 x = splat(w[u + t]);
+              o01 = pk_fma(x, f2{c4[4 * t + 3], c4[4 * t + 2]}, o01);
+              o23 = pk_fma(x, f2{c4[4 * t + 1], c4[4 * t]}, o23);
+            }
+            o01 *= splat(out_scale);
+            o23 *= splat(out_scale);
+            *reinterpret_cast<float4 *>(tr + 4 * (8 * lane + (u ^ (lane & 7)))) = make_float4(o01.x, o01.y, o23.x, o23.y);
+          }
+          wave_sync();
+          float *gO = gOf + 2048 * sg;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {  // float4 F = 64 i + lane: row F >> 3 = the source lane, column lane & 7
+            const int row = 8 * i + (lane >> 3);
+            const float4 t = lds4(tr + 4 * (8 * row + ((lane & 7) ^ (row & 7))));
+            stg_stream(gO + 256 * i + 4 * lane, t);
+          }
+        }
+      }
+      // the frame's last x2 outputs become the next frame's history: wave 0 is the only reader of
+      // YT[0] (segment 0, above)
+      if (wv == 0 && lane < 8) YT[lane] = YT[8 * R + lane];
+    }
   }
+#ifdef T41RX_STAMP
+  STAMP(13);
+  {
+    unsigned long long rt;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt)::"memory");
+    if (lane == 28) stamp_acc = stamp_t0;
+    if (lane == 29) stamp_acc = rt;
+    unsigned hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    if (lane == 27) stamp_acc = hwid | ((unsigned long long)(xcc & 0xf) << 32);
+  }
+  // behind the front kernel's stamps: [nchan][waves][64] uint64
+  if (a.dbg_demod)
+    reinterpret_cast<unsigned long long *>(a.dbg_demod + (size_t)a.nchan * a.nframes * 256)[(size_t)a.nchan * 64 + ((size_t)ch * NWV + wv) * 64 + lane] = stamp_acc;
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2654,12 +2829,22 @@ static hipError_t launch_long(const RxArgs &a, int mode, hipStream_t s) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   const bool cplx = a.agc || mode == T41RX_DEMOD_AM;
+  // real audio with the fixed gain, f32 samples out: the interpolators run behind pass 3 of the
+  // fast convolution (no `aud24` round trip, no third kernel)
+  static const bool fuse_env = [] { const char *e = std::getenv("T41RX_FUSE_BACK"); return !e || std::atoi(e) != 0; }();  // experiments
+  const bool fused = !cplx && !a.q15 && fuse_env;
 #define T41RX_FC(Rv)                                                                                             \
   do {                                                                                                           \
     if (cplx)                                                                                                    \
-      hipLaunchKernelGGL((fastconv_kernel<Rv, true>), dim3(a.nchan), dim3(256), fc_lds_floats(Rv) * sizeof(float), s, a); \
+      hipLaunchKernelGGL((fastconv_kernel<Rv, true>), dim3(a.nchan), dim3(64 * kFcWaves), fc_lds_floats(Rv) * sizeof(float), s, a); \
+    else if (fused) {                                                                                            \
+      static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&fastconv_kernel<Rv, false, true>), \
+          hipFuncAttributeMaxDynamicSharedMemorySize, fcb_lds_floats(Rv) * sizeof(float)); \
+      if (attr != hipSuccess) return attr;                                                                       \
+      hipLaunchKernelGGL((fastconv_kernel<Rv, false, true>), dim3(a.nchan), dim3(64 * kFcWaves), fcb_lds_floats(Rv) * sizeof(float), s, a); \
+    }                                                                                                            \
     else                                                                                                         \
-      hipLaunchKernelGGL((fastconv_kernel<Rv, false>), dim3(a.nchan), dim3(256), fc_lds_floats(Rv) * sizeof(float), s, a); \
+      hipLaunchKernelGGL((fastconv_kernel<Rv, false>), dim3(a.nchan), dim3(64 * kFcWaves), fc_lds_floats(Rv) * sizeof(float), s, a); \
   } while (0)
   if (a.seg == 8)
     T41RX_FC(8);
@@ -2669,7 +2854,7 @@ static hipError_t launch_long(const RxArgs &a, int mode, hipStream_t s) {
     T41RX_FC(2);
 #undef T41RX_FC
   e = hipGetLastError();
-  if (e != hipSuccess) return e;
+  if (e != hipSuccess || fused) return e;
 #define T41RX_BACK(MODEv, AGCv)                                                                                   \
   do {                                                                                                            \
     if (a.q15)                                                                                                    \

@@ -20,5 +20,5 @@ for CNT in "${PASSES[@]}"; do
   i=$((i+1))
   rocprofv3 --pmc $CNT --output-format csv -d $OUT/pass$i -o pmc -- python3 $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline "$@" > $OUT/pass$i.log 2>&1 || { echo "pass $i failed"; tail -5 $OUT/pass$i.log; }
 done
-python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py $OUT | tee $OUT/summary.txt
+for K in ${PMC_KERNELS:-rx512_kernel}; do echo "== $K"; python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py $OUT $K | tee $OUT/summary_$K.txt; done
 find $OUT -name "*.csv" -size +2M -delete

@@ -236,7 +236,7 @@ __device__ __forceinline__ void fft512(cf (&v)[8], const cf (&tw1)[7], const cf 
 // held in 28 registers across both transforms: the fused kernel carries the next frame's input
 // prefetch through its back end and has no registers to spare.  `mid()` runs between the first and
 // the second stage (the fused kernel requests the filter mask there).
-template <bool INV, int TW2S = 8, typename MID>  // TW2S: stride of the second twiddle set (8 = compacted [7][8], 64 = read out of tw1)
+template <bool INV, typename MID>
 __device__ __forceinline__ void fft512_ldstw(cf (&v)[8], const cf *tw1l, const cf *tw2l, float *__restrict__ xbuf,
                                              int lane, MID mid) {
   cf *xb = reinterpret_cast<cf *>(xbuf);
@@ -259,7 +259,7 @@ __device__ __forceinline__ void fft512_ldstw(cf (&v)[8], const cf *tw1l, const c
   dft8<INV>(v);
 #pragma unroll
   for (int q = 1; q < 8; ++q) {
-    const cf w = tw2l[TW2S * (q - 1)];
+    const cf w = tw2l[8 * (q - 1)];
     v[q] = INV ? cmulc(v[q], w) : cmul(v[q], w);
   }
   wave_sync();
@@ -2305,13 +2305,16 @@ constexpr int fc_lds_floats(int R) { return 2 * kFcRow * R + 2 * (448 + 56); }  
 // three, and 8 waves per channel bought 3 %), so what counts is how many channels a CU holds at
 // once -- and that every channel of the 1024-channel batch is resident in ONE round (3 per CU =
 // 768 slots left a second round at a third of the occupancy: 16 frame-times where 10.7 would do).
-// Fused kernel, R = 8: four workgroups per CU = 40 KiB each = [working array 36 KiB | tw1 3.5 KiB |
-// interpolator histories]; the frame's audio and then the output transposition buffers alias the
-// working array (one more barrier), the second twiddle set is read out of the first
-// (W64^(q l1) = W512^(8 q l1), the same doubles rounded: identical values).
+// Fused kernel, R = 8: four workgroups per CU = 40 KiB each = [working array 36 KiB | twiddles
+// 4 KiB] and nothing else: the frame's audio, then the output transposition buffers and the x4
+// interpolator's boundary samples alias the working array (one more barrier), and what crosses the
+// frames (24 audio samples, 7 x2 outputs) waits in two registers of wave 0.
+#ifndef T41RX_FCABL
+#define T41RX_FCABL 0  // timing experiments: 1 no output stores, 2 no 512-point FFTs, 4 no input loads, 8 no x4 arithmetic, 16 no x2 arithmetic
+#endif
 constexpr int kFcWaves = 4;
-constexpr int fc_arr_floats(int R) { return 2 * kFcRow * R < kFcWaves * 2048 ? kFcWaves * 2048 : 2 * kFcRow * R; }  // >= the four transposition buffers
-constexpr int fcb_lds_floats(int R) { return fc_arr_floats(R) + 2 * 448 + 32 + 8 * (R + 1); }
+constexpr int fc_arr_floats(int R) { return 2 * kFcRow * R < kFcWaves * 2048 + 8 * (R + 1) ? kFcWaves * 2048 + 8 * (R + 1) : 2 * kFcRow * R; }  // >= four transposition buffers + YT
+constexpr int fcb_lds_floats(int R) { return fc_arr_floats(R) + 2 * (448 + 56); }
 static_assert(fcb_lds_floats(8) * 4 * 4 <= 160 * 1024, "four fused workgroups per CU");
 template <int R, bool INV>
 __device__ __forceinline__ void dft_r(cf (&v)[R]) {
@@ -2355,17 +2358,15 @@ __global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_kern
   const int ch = blockIdx.x;
   if (ch >= a.nchan) return;
   cf *A = reinterpret_cast<cf *>(smem);
-  // behind the working array: the 512-point FFT's twiddles (tw1 [7][64]; BACK: tw2[q][l1] is
-  // tw1[q][8 l1], else compacted to [7][8] behind it), read at the point of use -- the registers
-  // they would occupy hold what must not wait for L2
+  // behind the working array: the 512-point FFT's twiddles (tw1 [7][64], tw2 compacted to [7][8]),
+  // read at the point of use -- the registers they would occupy hold what must not wait for L2
   constexpr int kArr = BACK ? fc_arr_floats(R) : 2 * kFcRow * R;
   cf *ltw = reinterpret_cast<cf *>(smem + kArr);
-  const cf *ltw2 = BACK ? ltw + 8 * (lane & 7) : ltw + 448 + (lane & 7);
-  constexpr int kTw2Stride = BACK ? 64 : 8;
-  float *AU = smem;                       // BACK, from pass 3 to the x2 interpolator: [0] pad, [1..23] history, [24 + i] audio sample i of the frame
-  float *HI = smem + kArr + 2 * 448;      // BACK: the frame's last 24 audio samples, [0] pad (= AU[0..23] of the next frame)
-  float *YT = HI + 32;                    // BACK: [s][0] pad, [s][1..7] = the last 7 x2 outputs before segment s
-  static_assert(!BACK || 24 + D + 8 <= kArr, "the audio fits where the working array was");
+  float *AU = smem;                    // BACK, from pass 3 to the x2 interpolator: [0] pad, [1..23] history, [24 + i] audio sample i of the frame
+  float *YT = smem + kFcWaves * 2048;  // BACK, behind the transposition buffers: [s][0] pad, [s][1..7] = the last 7 x2 outputs before segment s
+  static_assert(!BACK || 24 + D + 8 <= kFcWaves * 2048, "the audio fits where the working array was");
+  // BACK, wave 0: lane i < 24 = audio history entry i ([0] pad), lane i < 8 = x2 history entry i
+  float hi_reg = 0.0f, yt_reg = 0.0f;
   float *st = a.state + (size_t)ch * state_floats(N);
   const cf *twN = reinterpret_cast<const cf *>(a.tab4k);                    // [R-1][512]
   const cf *maskN = reinterpret_cast<const cf *>(a.tab4k) + (R - 1) * 512;  // [R][512]
@@ -2373,10 +2374,10 @@ __global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_kern
   const float fixed_gain = ((CoefPtr)a.coef)->sc[kScFixedGain];
 
   for (int i = threadIdx.x; i < 448; i += NT) ltw[i] = tab[kTabTw1 + i];
-  if (!BACK && threadIdx.x < 56) ltw[448 + threadIdx.x] = tab[kTabTw2 + 64 * (threadIdx.x >> 3) + (threadIdx.x & 7)];
+  if (threadIdx.x < 56) ltw[448 + threadIdx.x] = tab[kTabTw2 + 64 * (threadIdx.x >> 3) + (threadIdx.x & 7)];
   if (BACK) {  // interpolator memories of the channel
-    if (threadIdx.x < 24) HI[threadIdx.x] = st[kStInt1 + threadIdx.x];
-    else if (threadIdx.x >= 64 && threadIdx.x < 72) YT[threadIdx.x - 64] = st[kStInt2 + threadIdx.x - 64];
+    if (threadIdx.x < 24) hi_reg = st[kStInt1 + threadIdx.x];
+    if (threadIdx.x < 8) yt_reg = st[kStInt2 + threadIdx.x];
   }
   // the outer radix-R pass' twiddles of this wave's two column blocks (r = wv, wv + 4) stay in
   // registers for the whole call: passes 1 and 3 of every frame use the same ones
@@ -2395,26 +2396,25 @@ __global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_kern
     FRESH_LANE();
     // ---- overlap-save assemble (Process.cpp:498-522): [previous N/2 | new N/2].  Inside a call the
     // previous block is the preceding frame's `mid` (just read, L2-warm); the state record supplies
-    // it for the call's first frame and receives the last frame's block.
-    const float4 *mid = reinterpret_cast<const float4 *>(a.mid + ((size_t)ch * a.nframes4k + f) * (2 * D));
-    const float4 *prev = (f == 0) ? reinterpret_cast<const float4 *>(st + kStOverlap) : mid - N / 4;
-    float4 *A4 = reinterpret_cast<float4 *>(smem);
-    STAMP(0);         // (tail of the previous frame: stores issued, history rolled)
-    __syncthreads();  // the previous frame's pass 3 is done with the array (first frame: the twiddles are staged)
-    STAMP(1);
+    // it for the call's first frame and receives the last frame's block.  Pass 1 takes its inputs
+    // x[k + 512 p] straight from there (8 bytes per lane, 512 per instruction): the array is first
+    // written with pass 1's results.
+    const cf *mid = reinterpret_cast<const cf *>(a.mid + ((size_t)ch * a.nframes4k + f) * (2 * D));
+    const cf *prev = (f == 0) ? reinterpret_cast<const cf *>(st + kStOverlap) : mid - D;
+    cf x1[H][R];
 #pragma unroll
-    for (int i = wv; i < N / 256; i += NWV) {  // float4 = 2 complex; 256 float4 per row
-      const float4 p = prev[64 * i + lane];
-      const float4 n = mid[64 * i + lane];
-      const int e = 64 * i + lane;          // float4 index within a half (N/4 of them)
-      const int rp = e >> 8, rn = (e + N / 4) >> 8;
-      A4[rp * (kFcRow / 2) + (e & 255)] = p;
-      A4[rn * (kFcRow / 2) + ((e + N / 4) & 255)] = n;
-      if (f == a.nframes4k - 1) reinterpret_cast<float4 *>(st + kStOverlap)[64 * i + lane] = n;  // next call's "previous"
+    for (int h = 0; h < H; ++h) {
+      const int k = lane + 64 * (wv + NWV * h);
+#pragma unroll
+      for (int p = 0; p < R; ++p) {
+        const int e = k + 512 * p;  // index into [previous | new]
+        if (T41RX_FCABL & 4) x1[h][p] = cf{1.0f + lane, (float)f};
+        else x1[h][p] = (p < R / 2) ? prev[e] : mid[e - D];
+      }
     }
     // the filter mask of this wave's rows of pass 2 (q = wv, wv + 4): requested now, used two
     // barriers later, so its L2 round trip runs under pass 1
-    STAMP(2);  // assemble: global loads -> LDS
+    STAMP(2);
     cf mk[H][8];
 #pragma unroll
     for (int h = 0; h < H; ++h) {
@@ -2424,9 +2424,9 @@ __global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_kern
         for (int r = 0; r < 8; ++r) mk[h][r] = maskN[512 * q + lane + 64 * r];
       }
     }
-    STAMP(3);
-    __syncthreads();
-    STAMP(4);
+    STAMP(0);         // (tail of the previous frame: stores issued, history rolled)
+    __syncthreads();  // the previous frame's back end is done with the array (first frame: the twiddles are staged)
+    STAMP(1);
     FRESH_LANE();
     // ---- pass 1
 #pragma unroll
@@ -2434,7 +2434,11 @@ __global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_kern
       const int k = lane + 64 * (wv + NWV * h);
       cf v[R];
 #pragma unroll
-      for (int p = 0; p < R; ++p) v[p] = A[k + kFcRow * p];
+      for (int p = 0; p < R; ++p) v[p] = x1[h][p];
+      if (f == a.nframes4k - 1) {  // next call's "previous"
+#pragma unroll
+        for (int p = R / 2; p < R; ++p) reinterpret_cast<cf *>(st + kStOverlap)[k + 512 * p - D] = v[p];
+      }
       dft_r<R, false>(v);
 #pragma unroll
       for (int q = 1; q < R; ++q) v[q] = cmul(v[q], twp[h][q - 1]);
@@ -2455,10 +2459,10 @@ __global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_kern
         for (int r = 0; r < 8; ++r) v[r] = A[kFcRow * q + lane + 64 * r];
         float *xbuf = smem + 2 * kFcRow * q;  // the row itself (now in registers) is the exchange scratch
         wave_sync();
-        fft512_ldstw<false, kTw2Stride>(v, ltw + lane, ltw2, xbuf, lane, []() {});
+        if (!(T41RX_FCABL & 2)) fft512_ldstw<false>(v, ltw + lane, ltw + 448 + (lane & 7), xbuf, lane, []() {});
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] = cmul(v[r], mk[h][r]);
-        fft512_ldstw<true, kTw2Stride>(v, ltw + lane, ltw2, xbuf, lane, []() {});
+        if (!(T41RX_FCABL & 2)) fft512_ldstw<true>(v, ltw + lane, ltw + 448 + (lane & 7), xbuf, lane, []() {});
         wave_sync();
 #pragma unroll
         for (int r = 0; r < 8; ++r) A[kFcRow * q + lane + 64 * r] = v[r];
@@ -2501,11 +2505,12 @@ __global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_kern
       for (int h = 0; h < H; ++h)
 #pragma unroll
         for (int j = 0; j < R / 2; ++j) AU[24 + lane + 64 * (wv + NWV * h) + 512 * j] = y3[h][j];
-      if (threadIdx.x < 24) AU[threadIdx.x] = HI[threadIdx.x];
+      if (threadIdx.x < 24) AU[threadIdx.x] = hi_reg;
+      if (threadIdx.x < 8) YT[threadIdx.x] = yt_reg;
       __syncthreads();  // the frame's audio is complete
       STAMP(10);
       FRESH_LANE();
-      if (threadIdx.x < 24) HI[threadIdx.x] = AU[D + threadIdx.x];  // the next frame's history, before the transposition takes the place
+      if (threadIdx.x < 24) hi_reg = AU[D + threadIdx.x];  // the next frame's history, before the transposition takes the place
       // ---- interpolate by 2 (48 taps, phase length 24), segment s: inputs n = 4 lane .. 4 lane + 3
       f2 u1[H][4];  // outputs (2n, 2n+1) of input n = 4 lane + u
 #pragma unroll
@@ -2529,7 +2534,7 @@ __global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_kern
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
 #pragma unroll
-              for (int t = 0; t < 8; ++t) u1[h][u] = pk_fma(splat(w[u + b + t + 1]), f2{ci[2 * b + 1 + 2 * t], ci[2 * b + 2 * t]}, u1[h][u]);
+              for (int t = 0; t < ((T41RX_FCABL & 16) ? 1 : 8); ++t) u1[h][u] = pk_fma(splat(w[u + b + t + 1]), f2{ci[2 * b + 1 + 2 * t], ci[2 * b + 2 * t]}, u1[h][u]);
             }
           }
           if (lane == 63) {  // what the next segment's x4 interpolator remembers
@@ -2546,7 +2551,7 @@ __global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_kern
       STAMP(12);
       FRESH_LANE();
       if (f == a.nframes4k - 1) {  // the channel's interpolator memories after the call
-        if (threadIdx.x < 24) st[kStInt1 + threadIdx.x] = HI[threadIdx.x];
+        if (threadIdx.x < 24) st[kStInt1 + threadIdx.x] = hi_reg;
         else if (threadIdx.x >= 64 && threadIdx.x < 72) st[kStInt2 + threadIdx.x - 64] = YT[8 * R + threadIdx.x - 64];
       }
       // ---- interpolate by 4 (32 taps, phase length 8): inputs n = 8 lane .. 8 lane + 7; volume;
@@ -2572,7 +2577,7 @@ __global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_kern
           for (int u = 0; u < 8; ++u) {
             f2 o01 = splat(0.0f), o23 = splat(0.0f);
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
+            for (int t = 0; t < ((T41RX_FCABL & 8) ? 1 : 8); ++t) {
               const f2 x = splat(w[u + t]);
               o01 = pk_fma(x, f2{c4[4 * t + 3], c4[4 * t + 2]}, o01);
               o23 = pk_fma(x, f2{c4[4 * t + 1], c4[4 * t]}, o23);
@@ -2587,13 +2592,11 @@ __global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_kern
           for (int i = 0; i < 8; ++i) {  // float4 F = 64 i + lane: row F >> 3 = the source lane, column lane & 7
             const int row = 8 * i + (lane >> 3);
             const float4 t = lds4(tr + 4 * (8 * row + ((lane & 7) ^ (row & 7))));
-            stg_stream(gO + 256 * i + 4 * lane, t);
+            if (!(T41RX_FCABL & 1) || t.x == 123.456f) stg_stream(gO + 256 * i + 4 * lane, t);
           }
         }
       }
-      // the frame's last x2 outputs become the next frame's history: wave 0 is the only reader of
-      // YT[0] (segment 0, above)
-      if (wv == 0 && lane < 8) YT[lane] = YT[8 * R + lane];
+      if (threadIdx.x < 8) yt_reg = YT[8 * R + threadIdx.x];  // the frame's last x2 outputs: the next frame's history
     }
   }
 #ifdef T41RX_STAMP

@@ -277,6 +277,54 @@ __device__ __forceinline__ void fft512_ldstw(cf (&v)[8], const cf *tw1l, const c
   dft8<INV>(v);
 }
 
+// Two independent 512-point transforms in lockstep (the fast convolution's two rows per wave): the
+// second one's arithmetic fills the first one's LDS round trips -- a wave alone on its SIMD issues
+// nothing while it waits for an exchange, and that kernel is bound by exactly those waits.
+template <bool INV>
+__device__ __forceinline__ void fft512_ldstw_x2(cf (&v)[8], cf (&u)[8], const cf *tw1l, const cf *tw2l,
+                                                float *__restrict__ xbuf_v, float *__restrict__ xbuf_u, int lane) {
+  cf *xv = reinterpret_cast<cf *>(xbuf_v), *xu = reinterpret_cast<cf *>(xbuf_u);
+  const int l1 = lane & 7, q3 = lane >> 3;
+  dft8<INV>(v);
+  dft8<INV>(u);
+#pragma unroll
+  for (int q = 1; q < 8; ++q) {
+    const cf w = tw1l[64 * (q - 1)];
+    v[q] = INV ? cmulc(v[q], w) : cmul(v[q], w);
+    u[q] = INV ? cmulc(u[q], w) : cmul(u[q], w);
+  }
+  wave_sync();
+#pragma unroll
+  for (int q = 0; q < 8; ++q) xv[q * kFftRow + lane] = v[q];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) xu[q * kFftRow + lane] = u[q];
+  wave_sync();
+#pragma unroll
+  for (int k2 = 0; k2 < 8; ++k2) v[k2] = xv[q3 * kFftRow + l1 + 8 * k2];
+#pragma unroll
+  for (int k2 = 0; k2 < 8; ++k2) u[k2] = xu[q3 * kFftRow + l1 + 8 * k2];
+  dft8<INV>(v);
+  dft8<INV>(u);
+#pragma unroll
+  for (int q = 1; q < 8; ++q) {
+    const cf w = tw2l[8 * (q - 1)];
+    v[q] = INV ? cmulc(v[q], w) : cmul(v[q], w);
+    u[q] = INV ? cmulc(u[q], w) : cmul(u[q], w);
+  }
+  wave_sync();
+#pragma unroll
+  for (int q2 = 0; q2 < 8; ++q2) xv[q2 * kFftRow + q3 + fft_x2(l1)] = v[q2];
+#pragma unroll
+  for (int q2 = 0; q2 < 8; ++q2) xu[q2 * kFftRow + q3 + fft_x2(l1)] = u[q2];
+  wave_sync();
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = xv[q3 * kFftRow + l1 + fft_x2(j)];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) u[j] = xu[q3 * kFftRow + l1 + fft_x2(j)];
+  dft8<INV>(v);
+  dft8<INV>(u);
+}
+
 // ------------------------------------------------------------------------------------------
 // DC high-pass (HP_DC_Filter_Coeffs2, FIR.cpp:87-89): y = b0 x + d; d' = b1 x + a1 y  (b2=a2=0)
 // ------------------------------------------------------------------------------------------
@@ -2309,6 +2357,12 @@ constexpr int fc_lds_floats(int R) { return 2 * kFcRow * R + 2 * (448 + 56); }  
 // 4 KiB] and nothing else: the frame's audio, then the output transposition buffers and the x4
 // interpolator's boundary samples alias the working array (one more barrier), and what crosses the
 // frames (24 audio samples, 7 x2 outputs) waits in two registers of wave 0.
+#ifndef T41RX_FC_PRIO
+#define T41RX_FC_PRIO 1
+#endif
+#ifndef T41RX_FC_X2
+#define T41RX_FC_X2 1  // pass 2: the wave's two rows in lockstep
+#endif
 #ifndef T41RX_FCABL
 #define T41RX_FCABL 0  // timing experiments: 1 no output stores, 2 no 512-point FFTs, 4 no input loads, 8 no x4 arithmetic, 16 no x2 arithmetic
 #endif
@@ -2379,13 +2433,16 @@ __global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_kern
     if (threadIdx.x < 24) hi_reg = st[kStInt1 + threadIdx.x];
     if (threadIdx.x < 8) yt_reg = st[kStInt2 + threadIdx.x];
   }
-  // the outer radix-R pass' twiddles of this wave's two column blocks (r = wv, wv + 4) stay in
-  // registers for the whole call: passes 1 and 3 of every frame use the same ones
+  // the outer radix-R pass' twiddles of this wave's two column blocks (r = wv, wv + 4): re-read
+  // from L2 for passes 1 and 3 of every frame, requested ahead of the barrier in front of the pass
+  // (pass 2 wants the 28 registers they would hold)
   cf twp[H][R > 1 ? R - 1 : 1];
+  auto load_twp = [&]() {
 #pragma unroll
-  for (int h = 0; h < H; ++h)
+    for (int h = 0; h < H; ++h)
 #pragma unroll
-    for (int q = 1; q < R; ++q) twp[h][q - 1] = twN[512 * (q - 1) + lane + 64 * (wv + NWV * h)];
+      for (int q = 1; q < R; ++q) twp[h][q - 1] = twN[512 * (q - 1) + lane + 64 * (wv + NWV * h)];
+  };
 
 #ifdef T41RX_STAMP
   unsigned long long stamp_acc = 0, stamp_last, stamp_t0;
@@ -2394,6 +2451,17 @@ __global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_kern
 #endif
   for (int f = 0; f < a.nframes4k; ++f) {
     FRESH_LANE();
+#if T41RX_FC_PRIO
+    // issue priority falls with progress: the arbiter favours the oldest waves, so without it the
+    // first workgroup of a CU finishes long before the last (108 .. 195 us, stamps), which then
+    // runs alone -- and alone a workgroup is latency-bound
+    switch ((4 * f) / a.nframes4k) {
+      case 0: PRIO(3); break;
+      case 1: PRIO(2); break;
+      case 2: PRIO(1); break;
+      default: PRIO(0); break;
+    }
+#endif
     // ---- overlap-save assemble (Process.cpp:498-522): [previous N/2 | new N/2].  Inside a call the
     // previous block is the preceding frame's `mid` (just read, L2-warm); the state record supplies
     // it for the call's first frame and receives the last frame's block.  Pass 1 takes its inputs
@@ -2424,6 +2492,7 @@ __global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_kern
         for (int r = 0; r < 8; ++r) mk[h][r] = maskN[512 * q + lane + 64 * r];
       }
     }
+    load_twp();
     STAMP(0);         // (tail of the previous frame: stores issued, history rolled)
     __syncthreads();  // the previous frame's back end is done with the array (first frame: the twiddles are staged)
     STAMP(1);
@@ -2450,24 +2519,47 @@ __global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_kern
     STAMP(6);
     FRESH_LANE();
     // ---- pass 2: 512-point FFT, mask (pre-scaled by 1/N), inverse 512-point FFT, per q
+    if constexpr (R == 8 && H == 2 && T41RX_FC_X2) {  // both rows of the wave in lockstep
+      const int q0 = wv, q1 = wv + NWV;
+      cf v[8], u[8];
 #pragma unroll
-    for (int h = 0; h < H; ++h) {
-      const int q = wv + NWV * h;
-      if (q < R) {
-        cf v[8];
+      for (int r = 0; r < 8; ++r) v[r] = A[kFcRow * q0 + lane + 64 * r];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = A[kFcRow * q + lane + 64 * r];
-        float *xbuf = smem + 2 * kFcRow * q;  // the row itself (now in registers) is the exchange scratch
-        wave_sync();
-        if (!(T41RX_FCABL & 2)) fft512_ldstw<false>(v, ltw + lane, ltw + 448 + (lane & 7), xbuf, lane, []() {});
+      for (int r = 0; r < 8; ++r) u[r] = A[kFcRow * q1 + lane + 64 * r];
+      float *xv = smem + 2 * kFcRow * q0, *xu = smem + 2 * kFcRow * q1;  // the rows themselves (now in registers) are the exchange scratch
+      fft512_ldstw_x2<false>(v, u, ltw + lane, ltw + 448 + (lane & 7), xv, xu, lane);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = cmul(v[r], mk[h][r]);
-        if (!(T41RX_FCABL & 2)) fft512_ldstw<true>(v, ltw + lane, ltw + 448 + (lane & 7), xbuf, lane, []() {});
-        wave_sync();
+      for (int r = 0; r < 8; ++r) {
+        v[r] = cmul(v[r], mk[0][r]);
+        u[r] = cmul(u[r], mk[1][r]);
+      }
+      fft512_ldstw_x2<true>(v, u, ltw + lane, ltw + 448 + (lane & 7), xv, xu, lane);
+      wave_sync();
 #pragma unroll
-        for (int r = 0; r < 8; ++r) A[kFcRow * q + lane + 64 * r] = v[r];
+      for (int r = 0; r < 8; ++r) A[kFcRow * q0 + lane + 64 * r] = v[r];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) A[kFcRow * q1 + lane + 64 * r] = u[r];
+    } else {
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        const int q = wv + NWV * h;
+        if (q < R) {
+          cf v[8];
+#pragma unroll
+          for (int r = 0; r < 8; ++r) v[r] = A[kFcRow * q + lane + 64 * r];
+          float *xbuf = smem + 2 * kFcRow * q;  // the row itself (now in registers) is the exchange scratch
+          wave_sync();
+          if (!(T41RX_FCABL & 2)) fft512_ldstw<false>(v, ltw + lane, ltw + 448 + (lane & 7), xbuf, lane, []() {});
+#pragma unroll
+          for (int r = 0; r < 8; ++r) v[r] = cmul(v[r], mk[h][r]);
+          if (!(T41RX_FCABL & 2)) fft512_ldstw<true>(v, ltw + lane, ltw + 448 + (lane & 7), xbuf, lane, []() {});
+          wave_sync();
+#pragma unroll
+          for (int r = 0; r < 8; ++r) A[kFcRow * q + lane + 64 * r] = v[r];
+        }
       }
     }
+    load_twp();
     STAMP(7);
     __syncthreads();
     STAMP(8);

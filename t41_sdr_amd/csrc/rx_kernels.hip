@@ -2449,6 +2449,21 @@ __global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_kern
   asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_t0)::"memory");
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
 #endif
+  cf x1[H][R];
+  auto load_x1 = [&](int f) {
+    const cf *mid = reinterpret_cast<const cf *>(a.mid + ((size_t)ch * a.nframes4k + f) * (2 * D));
+    const cf *prev = (f == 0) ? reinterpret_cast<const cf *>(st + kStOverlap) : mid - D;
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      const int k = lane + 64 * (wv + NWV * h);
+#pragma unroll
+      for (int p = 0; p < R; ++p) {
+        const int e = k + 512 * p;  // index into [previous | new]
+        if (T41RX_FCABL & 4) x1[h][p] = cf{1.0f + lane, (float)f};
+        else x1[h][p] = (p < R / 2) ? prev[e] : mid[e - D];
+      }
+    }
+  };
   for (int f = 0; f < a.nframes4k; ++f) {
     FRESH_LANE();
 #if T41RX_FC_PRIO
@@ -2467,31 +2482,10 @@ __global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_kern
     // it for the call's first frame and receives the last frame's block.  Pass 1 takes its inputs
     // x[k + 512 p] straight from there (8 bytes per lane, 512 per instruction): the array is first
     // written with pass 1's results.
-    const cf *mid = reinterpret_cast<const cf *>(a.mid + ((size_t)ch * a.nframes4k + f) * (2 * D));
-    const cf *prev = (f == 0) ? reinterpret_cast<const cf *>(st + kStOverlap) : mid - D;
-    cf x1[H][R];
-#pragma unroll
-    for (int h = 0; h < H; ++h) {
-      const int k = lane + 64 * (wv + NWV * h);
-#pragma unroll
-      for (int p = 0; p < R; ++p) {
-        const int e = k + 512 * p;  // index into [previous | new]
-        if (T41RX_FCABL & 4) x1[h][p] = cf{1.0f + lane, (float)f};
-        else x1[h][p] = (p < R / 2) ? prev[e] : mid[e - D];
-      }
-    }
-    // the filter mask of this wave's rows of pass 2 (q = wv, wv + 4): requested now, used two
-    // barriers later, so its L2 round trip runs under pass 1
+    // (requesting the next frame's inputs before the back end instead -- the registers are there --
+    // measured 1..3 % slower: the loads queue up behind the back end's 64 KiB of stores)
+    load_x1(f);
     STAMP(2);
-    cf mk[H][8];
-#pragma unroll
-    for (int h = 0; h < H; ++h) {
-      const int q = wv + NWV * h;
-      if (q < R) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) mk[h][r] = maskN[512 * q + lane + 64 * r];
-      }
-    }
     load_twp();
     STAMP(0);         // (tail of the previous frame: stores issued, history rolled)
     __syncthreads();  // the previous frame's back end is done with the array (first frame: the twiddles are staged)
@@ -2513,6 +2507,17 @@ __global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_kern
       for (int q = 1; q < R; ++q) v[q] = cmul(v[q], twp[h][q - 1]);
 #pragma unroll
       for (int q = 0; q < R; ++q) A[k + kFcRow * q] = v[q];
+    }
+    // the filter mask of this wave's rows of pass 2 (q = wv, wv + 4): requested here, so its L2
+    // round trip runs under the barrier and the forward FFTs
+    cf mk[H][8];
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      const int q = wv + NWV * h;
+      if (q < R) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) mk[h][r] = maskN[512 * q + lane + 64 * r];
+      }
     }
     STAMP(5);
     __syncthreads();

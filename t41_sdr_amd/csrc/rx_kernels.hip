@@ -932,8 +932,15 @@ __device__ __forceinline__ void agc_apply(const cf (&v)[8], float4 agst, float *
     // All 64 lanes stay enabled (lane l redoes channel l mod nvalid): measured on MI355X
     // (tools/ubench/exec_mask.hip), VALU instructions of a wave with 16 or fewer active lanes
     // take 3-4x longer than with 32 or more.
-    if (wv == cw)
+    // The chain is the frame's critical path -- three waves wait for it -- and one dependent
+    // instruction at a time: it gets the top issue priority (the other phases of these kernels
+    // stay at 2 and below), or every one of its ~10 k instructions queues behind the parallel
+    // phases of the other workgroups' waves on its SIMD (51 k cycles per frame, stamps).
+    if (wv == cw) {
+      PRIO(3);
       agc_chain<AL>(slices + (nvalid == NW ? (lane & (NW - 1)) : lane % nvalid) * SLICE, cf0, lane STAMP_ARGS);
+      PRIO(1);
+    }
     STAMP(21);  // AGC: the serial chain (chain wave only)
     __syncthreads();
     STAMP(22);  // AGC: barrier 2 (= waiting for the chain, for the other waves)
@@ -1178,7 +1185,7 @@ __global__ __launch_bounds__((Geo<PART, AGC>::kWaves * 64), 4) void rx512_kernel
     }
   };
   for (int f = seg0; f < seg1; ++f) {
-    PRIO(3);
+    if (AGC) PRIO(2); else PRIO(3);  // (AGC on: 3 is the serial chain's, see agc_apply)
     FRESH_LANE();
     const bool first_iter = (f == seg0);
     const size_t fbase = ((size_t)(T41RX_ABLATE == 9 ? (ch & 15) : ch) * a.nframes + f) * L;
@@ -1643,7 +1650,7 @@ __global__ __launch_bounds__((Geo<PART, AGC>::kWaves * 64), 4) void rx512_kernel
           }
         }  // h
         STAMP(4);  // history roll
-        if (rd == 1) PRIO(2);
+        if (rd == 1) { if (AGC) PRIO(1); else PRIO(2); }
       // ---- decimate by 2 (46 taps) over the 256 new /4 samples: m = 2*lane, 2*lane+1
         wave_sync();
         // y[m] = sum_i c[i] * state[2m + i]; state[i] = buf[i + 3]

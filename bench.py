@@ -59,7 +59,7 @@ WORKLOADS = {
     "ssb_q15": dict(batch=4096, fft=512, kw=dict(mode=0, FLoCut=200, FHiCut=3000), q15=True,
                     name="configs[1] on the firmware's own sample format either side (q15 record-queue blocks in, "
                          "arm_float_to_q15 out; Process.cpp:102-111, 936): 6 B per input complex sample (SURVEY 8f rank 3)"),
-    "fft4096": dict(batch=1024, fft=4096, kw=dict(mode=0, FLoCut=400, FHiCut=600), frames=8,
+    "fft4096": dict(batch=1024, fft=4096, kw=dict(mode=0, FLoCut=400, FHiCut=600), frames=16,
                     name="configs[3]: PSK31-like narrow USB filter, 4096-pt fast-conv (synthetic generalisation), "
                          "1024 channels x 16384 samples per frame"),
 }

@@ -53,6 +53,9 @@ WORKLOADS = {
     "am": dict(batch=4096, fft=512, kw=dict(mode=2, FLoCut=-3000, FHiCut=3000),
                name="AM path (AlphaBetaMag envelope, DC block, biquad low-pass; Process.cpp:697-707), 4096 channels x 2048 "
                     "samples per frame"),
+    "sam": dict(batch=4096, fft=512, kw=dict(mode=8, FLoCut=-3000, FHiCut=3000), frames=8,
+                name="synchronous AM (AMDecodeSAM, Demod.cpp:40-139: a per-sample PLL, serial in time; SURVEY 8f rank 4), "
+                     "4096 channels x 2048 samples per frame"),
     "ssb_agc": dict(batch=4096, fft=512, kw=dict(mode=0, FLoCut=200, FHiCut=3000, AGCMode=1),
                     name="configs[1] with the firmware's default AGCMode = 1 (look-ahead AGC, DSP_Fn.cpp:504-631) instead of "
                          "the fixed gain: 4096 channels x 2048 samples per frame (SURVEY 8f rank 1)"),
@@ -163,6 +166,9 @@ def synth_ring(torch, n_channels, nco_hz, ring, frames, frame_len, device, seed,
     phases = 2 * np.pi * torch.rand(n_channels, 3, generator=g, device=device, dtype=torch.float64)
     audio = 400.0 + 2100.0 * torch.rand(n_channels, generator=g, device=device, dtype=torch.float64)
     freqs[:, 0] = 48000.0 - nco - audio  # lands at +audio Hz in the USB pass band (I sign flip, +Fs/4, -NCO)
+    if mode == 8:  # SAM: the first tone is the carrier, 100 Hz off the tuned frequency
+        freqs[:, 0] = 48000.0 - nco - 100.0
+        amps[:, 0] = 0.3
     if mode == 3:  # NFM: no I sign flip; put a carrier on the tuned frequency
         freqs[:, 0] = -48000.0 + nco
         amps[:, 0] = 0.3

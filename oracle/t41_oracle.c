@@ -470,6 +470,7 @@ struct t41o_channel {
   float lp1_state[4];                 /* biquad_lowpass1_state, T41_SDR.ino:373 */
   float nfm_last_i, nfm_last_q;       /* Demod.cpp:221-222 */
   float nfm_last_phase;               /* fmdemod_atan_cf's static, Demod.cpp:373 */
+  float sam_phzerror, sam_fil_out, sam_omega2; /* AMDecodeSAM's PLL statics, Demod.cpp:19-23 */
   /* AGC() statics and globals, DSP_Fn.cpp:28-36, 481-492 */
   uint8_t agc_decay_type, agc_state;
   float *agc_abs_ring, *agc_ring;     /* [RB_SIZE], [2*RB_SIZE] */
@@ -585,6 +586,7 @@ void t41o_channel_reset(t41o_channel *ch) {
   memset(ch->lp1_state, 0, sizeof(ch->lp1_state));
   ch->nfm_last_i = ch->nfm_last_q = 0.0f;
   ch->nfm_last_phase = 0.0f;
+  ch->sam_phzerror = ch->sam_fil_out = ch->sam_omega2 = 0.0f;
   /* DSP_Fn.cpp:32-36, 481-492 */
   ch->agc_decay_type = 0;
   ch->agc_state = 0;
@@ -820,6 +822,115 @@ static float ApproxAtan2(float y, float x) {
     else if (y < 0.0f) return -T41O_TPI;
   }
   return 0.0f;
+}
+
+/* ---- arm_sin_f32 / arm_cos_f32 (CMSIS-DSP FastMathFunctions, the 512-entry table with linear
+ * interpolation that CMSIS-DSP has shipped since 1.4.5): in = x / (2 pi) [+ 0.25 for the cosine],
+ * reduced to [0, 1) by truncation, index = (uint16_t)(512 in), result = (1 - fract) T[index] +
+ * fract T[index + 1].  The library's table is a list of 8-decimal literals that is not in this
+ * container: T[k] here = sin(2 pi k / 512) evaluated in double and rounded to f32 (a CHOICE, like
+ * the other CMSIS conventions listed in DESIGN.md section 2: parity unpinned). */
+#define FAST_MATH_TABLE_SIZE 512
+static float sinTable_f32[FAST_MATH_TABLE_SIZE + 1];
+static int sinTable_ready = 0;
+static void sinTable_init(void) {
+  if (sinTable_ready) return;
+  for (int k = 0; k <= FAST_MATH_TABLE_SIZE; k++)
+    sinTable_f32[k] = (float)sin(6.283185307179586476925286766559 * (double)k / (double)FAST_MATH_TABLE_SIZE);
+  sinTable_f32[0] = 0.0f;
+  sinTable_f32[FAST_MATH_TABLE_SIZE / 2] = 0.0f; /* the library's table has exact zeros there (and -0.0f at the end) */
+  sinTable_f32[FAST_MATH_TABLE_SIZE] = -0.0f;
+  sinTable_ready = 1;
+}
+const float *t41o_sin_table(void) { sinTable_init(); return sinTable_f32; }
+static float fast_sincos_f32(float in) { /* the part arm_sin_f32 and arm_cos_f32 share */
+  int32_t n = (int32_t)in;
+  if (in < 0.0f) n--;
+  in = in - (float)n;
+  float findex = (float)FAST_MATH_TABLE_SIZE * in;
+  uint16_t index = (uint16_t)findex;
+  if (index >= FAST_MATH_TABLE_SIZE) {
+    index = 0;
+    findex -= (float)FAST_MATH_TABLE_SIZE;
+  }
+  float fract = findex - (float)index;
+  float a = sinTable_f32[index], b = sinTable_f32[index + 1];
+  return (1.0f - fract) * a + fract * b;
+}
+float t41o_arm_sin_f32(float x) { sinTable_init(); return fast_sincos_f32(x * 0.159154943092f); }
+float t41o_arm_cos_f32(float x) { sinTable_init(); return fast_sincos_f32(x * 0.159154943092f + 0.25f); }
+
+/* AMDecodeSAM(), Demod.cpp:40-139, with the file-scope PLL constants of Demod.cpp:13-23 evaluated as
+ * the C++ there evaluates them (gwv.cpp:64-65: omegaN = 200, pll_fmax = 4000, constant-initialised,
+ * so they hold those values when Demod.cpp's dynamic initialisers run).  As written:
+ *  - `exp(-1 / 24000 * tauR)`: -1 / 24000 is an integer division = 0, so mtauR = mtauI = 1 and the
+ *    "fade leveler" adds dc_insert - dc = 0 - 0 to every sample;
+ *  - ApproxAtan2 returns +-2 pi where +-pi/2 is meant (App. C #8): the phase detector jumps whenever
+ *    |corr[1]| >= |corr[0]|;
+ *  - float_buffer_R receives audiou = 0 (it is not played); the carrier display arithmetic behind the
+ *    loop is display code. */
+static void AMDecodeSAM(t41o_channel *ch, const float *iFFT_buffer, float *float_buffer_L, float *float_buffer_R, int FFT_length) {
+  const float omegaN = 200.0f, pll_fmax = +4000.0f; /* gwv.cpp:64-65 */
+  int zeta_help = 65;
+  float zeta = (float)zeta_help / 100.0;
+  float omega_min = T41O_TPI * -pll_fmax * 1 / 24000;
+  float omega_max = T41O_TPI * pll_fmax * 1 / 24000;
+  float g1 = 1.0 - exp(-2.0 * omegaN * zeta * 1 / 24000);
+  float g2 = -g1 + 2.0 * (1 - exp(-omegaN * zeta * 1 / 24000) * cosf(omegaN * 1 / 24000 * sqrtf(1.0 - zeta * zeta)));
+  float tauR = 0.02;
+  float tauI = 1.4;
+  float dc = 0.0, dc_insert = 0.0, dcu = 0.0, dc_insertu = 0.0;
+  float mtauR = exp(-1 / 24000 * tauR);
+  float onem_mtauR = 1.0 - mtauR;
+  float mtauI = exp(-1 / 24000 * tauI);
+  float onem_mtauI = 1.0 - mtauI;
+  float phzerror = ch->sam_phzerror, fil_out = ch->sam_fil_out, omega2 = ch->sam_omega2;
+  float det, del_out;
+  sinTable_init();
+  for (int i = 0; i < FFT_length / 2; i++) {
+    float Sin, Cos, ai, bi, aq, bq, audio, audiou = 0, corr[2];
+    Sin = t41o_arm_sin_f32(phzerror);
+    Cos = t41o_arm_cos_f32(phzerror);
+    ai = Cos * iFFT_buffer[FFT_length + i * 2];
+    bi = Sin * iFFT_buffer[FFT_length + i * 2];
+    aq = Cos * iFFT_buffer[FFT_length + i * 2 + 1];
+    bq = Sin * iFFT_buffer[FFT_length + i * 2 + 1];
+    corr[0] = +ai + bq;
+    corr[1] = -bi + aq;
+    audio = (ai - bi) + (aq + bq);
+    /* fade_leveler = 1 */
+    dc = mtauR * dc + onem_mtauR * audio;
+    dc_insert = mtauI * dc_insert + onem_mtauI * corr[0];
+    audio = audio + dc_insert - dc;
+    float_buffer_L[i] = audio;
+    dcu = mtauR * dcu + onem_mtauR * audiou;
+    dc_insertu = mtauI * dc_insertu + onem_mtauI * corr[0];
+    audiou = audiou + dc_insertu - dcu;
+    float_buffer_R[i] = audiou;
+    det = ApproxAtan2(corr[1], corr[0]);
+    del_out = fil_out;
+    omega2 = omega2 + g2 * det;
+    if (omega2 < omega_min) omega2 = omega_min;
+    else if (omega2 > omega_max) omega2 = omega_max;
+    fil_out = g1 * det + omega2;
+    phzerror = phzerror + del_out;
+    while (phzerror >= T41O_TPI) phzerror -= T41O_TPI;
+    while (phzerror < 0.0) phzerror += T41O_TPI;
+  }
+  ch->sam_phzerror = phzerror;
+  ch->sam_fil_out = fil_out;
+  ch->sam_omega2 = omega2;
+}
+/* the PLL constants as the product's designer must reproduce them: {omega_min, omega_max, g1, g2} */
+void t41o_sam_constants(float out[4]) {
+  const float omegaN = 200.0f, pll_fmax = +4000.0f;
+  int zeta_help = 65;
+  float zeta = (float)zeta_help / 100.0;
+  out[0] = T41O_TPI * -pll_fmax * 1 / 24000;
+  out[1] = T41O_TPI * pll_fmax * 1 / 24000;
+  float g1 = 1.0 - exp(-2.0 * omegaN * zeta * 1 / 24000);
+  out[2] = g1;
+  out[3] = -g1 + 2.0 * (1 - exp(-omegaN * zeta * 1 / 24000) * cosf(omegaN * 1 / 24000 * sqrtf(1.0 - zeta * zeta)));
 }
 
 /* Demod.cpp:368-392 */
@@ -1079,7 +1190,7 @@ int t41o_process_frame(t41o_channel *ch, const t41o_params *p, const t41o_coeffs
   if (p->fft_length != N) return -1;
   if (p->AGCMode < 0 || p->AGCMode > 4) return -2;
   const int mode = p->mode;
-  if (mode < T41O_DEMOD_USB || mode > T41O_DEMOD_NFM) return -3;
+  if ((mode < T41O_DEMOD_USB || mode > T41O_DEMOD_NFM) && mode != T41O_DEMOD_SAM) return -3;
   float *fL = ch->float_buffer_L, *fR = ch->float_buffer_R;
   float *exL = ch->float_buffer_L_EX, *exR = ch->float_buffer_R_EX;
   float *FFT_buffer = ch->FFT_buffer, *iFFT_buffer = ch->iFFT_buffer;
@@ -1105,7 +1216,7 @@ int t41o_process_frame(t41o_channel *ch, const t41o_params *p, const t41o_coeffs
   }
 
   /* Process.cpp:165-173: USB, LSB, AM (and SAM) only */
-  if (mode == T41O_DEMOD_LSB || mode == T41O_DEMOD_AM || mode == T41O_DEMOD_USB) {
+  if (mode == T41O_DEMOD_LSB || mode == T41O_DEMOD_AM || mode == T41O_DEMOD_USB || mode == T41O_DEMOD_SAM) {
     float s = -p->IQAmpCorrectionFactor;
     for (int i = 0; i < L; i++) fL[i] = fL[i] * s;
     float factor = p->IQPhaseCorrectionFactor; /* Utility.cpp:178-187 */
@@ -1234,6 +1345,9 @@ int t41o_process_frame(t41o_channel *ch, const t41o_params *p, const t41o_coeffs
       }
       t41o_biquad_df1_f32(c->biquad_lowpass1, ch->lp1_state, fL, fR, D); /* Process.cpp:705 */
       memcpy(fL, fR, sizeof(float) * (size_t)D);
+      break;
+    case T41O_DEMOD_SAM:
+      AMDecodeSAM(ch, iFFT_buffer, fL, fR, N); /* Process.cpp:754-755 */
       break;
     case T41O_DEMOD_NFM:
       if (p->nfm_demod == 1) fmdemod_atan_cf(ch, &FFT_buffer[N], fL, D); /* the commented-out alternative */

@@ -31,7 +31,8 @@ enum {
   T41O_DEMOD_USB = 0,
   T41O_DEMOD_LSB = 1,
   T41O_DEMOD_AM  = 2,
-  T41O_DEMOD_NFM = 3
+  T41O_DEMOD_NFM = 3,
+  T41O_DEMOD_SAM = 8 /* SDT.h:67 */
 };
 
 /* xmtMode, SDT.h:48-50 */
@@ -113,6 +114,13 @@ void t41o_biquad_df2T_f32(const float coeffs[5], float state[2], const float *sr
                           int n);
 void t41o_biquad_df1_f32(const float coeffs[5], float state[4], const float *src, float *dst,
                          int n);
+
+/* arm_sin_f32 / arm_cos_f32 as restated for AMDecodeSAM (Demod.cpp:75-76), their 513-entry table, and the PLL
+ * constants of Demod.cpp:13-18 {omega_min, omega_max, g1, g2} */
+float t41o_arm_sin_f32(float x);
+float t41o_arm_cos_f32(float x);
+const float *t41o_sin_table(void);
+void t41o_sam_constants(float out[4]);
 
 /* ---- channel state + the block function ---- */
 t41o_channel *t41o_channel_create(int fft_length);

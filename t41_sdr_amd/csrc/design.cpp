@@ -215,8 +215,9 @@ bool params_valid(const t41rx_params &p, const char **why) {
   };
   if (!(p.fft_length == 512 || p.fft_length == 1024 || p.fft_length == 2048 || p.fft_length == 4096))
     return fail("fft_length must be 512, 1024, 2048 or 4096");
-  if (p.mode < T41RX_DEMOD_USB || p.mode > T41RX_DEMOD_NFM)
-    return fail("mode must be USB, LSB, AM or NFM");
+  if ((p.mode < T41RX_DEMOD_USB || p.mode > T41RX_DEMOD_NFM) && p.mode != T41RX_DEMOD_SAM)
+    return fail("mode must be USB, LSB, AM, NFM or SAM");
+  if (p.mode == T41RX_DEMOD_SAM && p.fft_length != 512) return fail("SAM is built for fft_length 512");
   if (p.FHiCut <= p.FLoCut) return fail("FHiCut must be greater than FLoCut");
   if (p.FHiCut > 12000 || p.FLoCut < -12000) return fail("filter cut-offs beyond +-12 kHz (24 kS/s Nyquist)");
   if (p.mode == T41RX_DEMOD_LSB && p.FLoCut >= 0) return fail("LSB needs FLoCut < 0 (level adjust uses pow(-FLoCut))");
@@ -303,7 +304,7 @@ int design_blob(const t41rx_params &p, void *blob, size_t blob_bytes) {
     const float ampl = 5 * x * x * x * x * x;
     s[kScOutScale] = kDF * ampl;  // Process.cpp:929
   }
-  s[kScIqCorrOn] = (p.mode == T41RX_DEMOD_USB || p.mode == T41RX_DEMOD_LSB || p.mode == T41RX_DEMOD_AM) ? 1.0f : 0.0f;
+  s[kScIqCorrOn] = (p.mode == T41RX_DEMOD_USB || p.mode == T41RX_DEMOD_LSB || p.mode == T41RX_DEMOD_AM || p.mode == T41RX_DEMOD_SAM) ? 1.0f : 0.0f;
   {
     int side = 0;  // Freq_Shift.cpp:108-120
     if (p.xmtMode == T41RX_CW_MODE) {
@@ -313,6 +314,20 @@ int design_blob(const t41rx_params &p, void *blob, size_t blob_bytes) {
     s[kScSideTone] = (float)side;
   }
   s[kScNfmDemod] = (float)p.nfm_demod;
+  {
+    // The synchronous detector's PLL constants, Demod.cpp:13-18, with the types of that file's
+    // expressions (float globals, int and double literals) and gwv.cpp:64-65's omegaN = 200,
+    // pll_fmax = 4000, which are constant-initialised and therefore in place when these run.
+    const float TPI = 6.283185307179586476925286766559f;  // FIR.h:12-13
+    const float omegaN = 200.0f, pll_fmax = +4000.0f;
+    const int zeta_help = 65;
+    const float zeta = (float)zeta_help / 100.0;
+    s[kScSamWmin] = TPI * -pll_fmax * 1 / 24000;
+    s[kScSamWmax] = TPI * pll_fmax * 1 / 24000;
+    const float g1 = 1.0 - std::exp(-2.0 * omegaN * zeta * 1 / 24000);
+    s[kScSamG1] = g1;
+    s[kScSamG2] = -g1 + 2.0 * (1 - std::exp(-omegaN * zeta * 1 / 24000) * cosf(omegaN * 1 / 24000 * sqrtf(1.0 - zeta * zeta)));
+  }
   return T41RX_OK;
 }
 

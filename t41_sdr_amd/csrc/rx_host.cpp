@@ -204,6 +204,15 @@ int upload_coeffs(t41rx_ctx *ctx) {
       e[5] = make_float2(Q31.c, Q31.d);
     }
   }
+  // arm_sin_f32's table for the synchronous detector (Demod.cpp:75-76): sin(2 pi k / 512), k = 0..512, rounded from
+  // double (the library's own literals are not available here: DESIGN.md section 2), exact zeros where it has them
+  {
+    float *t = reinterpret_cast<float *>(&tab[(size_t)kTabSam]);
+    for (int k = 0; k <= 512; ++k) t[k] = (float)std::sin(6.283185307179586476925286766559 * (double)k / 512.0);
+    t[0] = 0.0f;
+    t[256] = 0.0f;
+    t[512] = -0.0f;
+  }
   HIP_TRY(hipMemcpy(ctx->d_tab, tab.data(), sizeof(float2) * tab.size(), hipMemcpyHostToDevice));
   return T41RX_OK;
 }
@@ -392,7 +401,7 @@ int t41rx_set_coeffs(t41rx_ctx *ctx, const void *blob, size_t blob_bytes) {
   const int32_t *h = reinterpret_cast<const int32_t *>(blob);
   if ((uint32_t)h[0] != kBlobMagic || h[1] != T41RX_ABI_VERSION) return fail(T41RX_ERR_STATE, "bad blob header");
   if (h[2] != ctx->params.fft_length) return fail(T41RX_ERR_STATE, "blob fft_length differs from the context");
-  if (h[3] < T41RX_DEMOD_USB || h[3] > T41RX_DEMOD_NFM) return fail(T41RX_ERR_STATE, "bad demodulation mode in blob");
+  if ((h[3] < T41RX_DEMOD_USB || h[3] > T41RX_DEMOD_NFM) && h[3] != T41RX_DEMOD_SAM) return fail(T41RX_ERR_STATE, "bad demodulation mode in blob");
   // the parameters the blob was designed for become the context's (every rank that installs a
   // broadcast blob then runs -- and later re-designs from -- the designer's parameters)
   if (h[4] != (int32_t)sizeof(t41rx_params)) return fail(T41RX_ERR_STATE, "blob carries another t41rx_params layout");
@@ -503,6 +512,7 @@ int process_device_impl(t41rx_ctx *ctx, const float *dI, const float *dQ, float 
     a.plain = ((iq_on ? gi == -1.0f : gi == 1.0f) && sc[kScBandGain] == 1.0f && (!iq_on || sc[kScIqPhase] == 0.0f)) ? 1 : 0;
   }
   a.q15 = q15 ? 1 : 0;
+  if (q15 && ctx->params.mode == T41RX_DEMOD_SAM) return fail(T41RX_ERR_UNSUPPORTED, "SAM is built for the f32 entry points");
   a.nco_rd = ctx->nco_sel;
   a.nfm_atan = (ctx->params.mode == T41RX_DEMOD_NFM && ctx->params.nfm_demod == 1) ? 1 : 0;
   if (a.nfm_atan && seg > 1) return fail(T41RX_ERR_UNSUPPORTED, "nfm_demod = 1 is built for fft_length 512");

@@ -21,7 +21,7 @@ constexpr uint32_t kBlobMagic = 0x54343152u;  // "T41R"
 // broadcast path) takes its parameters from here, so every rank ends up with the designer's.
 constexpr int kBlobHeaderInts = 8 + 16;
 static_assert(sizeof(t41rx_params) <= 16 * sizeof(int32_t), "params section of the blob header");
-constexpr int kNumScalars = 11;
+constexpr int kNumScalars = 16;
 enum Scalar {
   kScRfGain = 0,      // (float)pow(10, rfGainAllBands/20), Process.cpp:117
   kScBandGain = 1,    // (float)bands[].RFgain, Process.cpp:133
@@ -33,6 +33,10 @@ enum Scalar {
   kScIqCorrOn = 7,    // 1 when mode in {USB, LSB, AM}, Process.cpp:165-173
   kScSideTone = 8,    // sideToneShift [Hz], Freq_Shift.cpp:108-120
   kScNfmDemod = 9,    // t41rx_params::nfm_demod (0 quadri-correlator, 1 atan2 + de-emphasis)
+  kScSamWmin = 10,    // SAM PLL: omega_min, omega_max, g1, g2 (Demod.cpp:15-18)
+  kScSamWmax = 11,
+  kScSamG1 = 12,
+  kScSamG2 = 13,
 };
 // deemphasis_nfm_predefined_fir_24000 (Demod.cpp:324-325), a fixed table of the reference
 constexpr int kDeemphTaps = 81;
@@ -122,6 +126,9 @@ constexpr int kMiscNfmQ = 5;
 constexpr int kMiscNfmPhase = 6; // fmdemod_atan_cf's last_phase (nfm_demod = 1), Demod.cpp:373
 constexpr int kMiscLp1 = 8;     // biquad_lowpass1_state[4]
 constexpr int kMiscMaxSqAve = 12; // audioMaxSquaredAve, Process.cpp:570
+constexpr int kMiscSamPhz = 13;   // AMDecodeSAM's PLL statics phzerror, fil_out, omega2, Demod.cpp:19-23
+constexpr int kMiscSamFil = 14;
+constexpr int kMiscSamOmega = 15;
 constexpr int kStNco = 200;     // 8 floats = two NcoState (16 B each); FFT_LENGTH 512 uses the first, the long
                                 // FFT lengths alternate between them from call to call (rx_kernels.hip)
 constexpr int kStOverlap = 256; // fft_length floats: last_sample_buffer_L/R as [k][lane] (re,im)

@@ -810,6 +810,75 @@ __device__ __forceinline__ lanemask agc_fast_block(AgcState &st, AgcLane &d, con
   return ok;
 }
 
+// ---- AMDecodeSAM's loop (Demod.cpp:69-117) for one channel per lane: zs = the channel's 256 complex samples
+// (audio replaces the real parts), T = arm_sin_f32's table in LDS, ms = the channel's kStMisc words.
+// As written there: the fade leveler's time constants are exp(-1 / 24000 * tau) = exp(0) = 1 (integer
+// division), so it adds dc_insert - dc = 0 to the audio; ApproxAtan2 returns +-2 pi where +-pi/2 is
+// meant.  arm_sin_f32 / arm_cos_f32: 512-entry table, linear interpolation (CMSIS-DSP >= 1.4.5).
+__device__ __forceinline__ float sam_fast_sine(float in, const float *T) {
+#pragma clang fp contract(off)
+  int n = (int)in;
+  if (in < 0.0f) n--;
+  in = in - (float)n;
+  float findex = 512.0f * in;
+  unsigned index = (unsigned)findex & 0xffffu;  // (uint16_t)
+  if (index >= 512u) {
+    index = 0;
+    findex -= 512.0f;
+  }
+  const float fract = findex - (float)index;
+  const float a = T[index], b = T[index + 1];
+  return (1.0f - fract) * a + fract * b;
+}
+__device__ __forceinline__ float sam_atan(float z) {  // ApproxAtan, Utility.cpp:298-302
+#pragma clang fp contract(off)
+  const float n1 = 0.97239411f, n2 = -0.19194795f;
+  return (n1 + n2 * z * z) * z;
+}
+__device__ __forceinline__ float sam_atan2(float y, float x) {  // ApproxAtan2, Demod.cpp:148-197, branch-free
+#pragma clang fp contract(off)
+  const float kPi = 3.1415926535897932384626433832795f, kTpi = 6.283185307179586476925286766559f;
+  const bool xg = fabsf(x) > fabsf(y);           // the branch that divides y / x; else x / y
+  const float t = sam_atan((xg ? y : x) / (xg ? x : y));  // one division, the operands the taken branch has
+  const float rx = x > 0.0f ? t : (y >= 0.0f ? t + kPi : t - kPi);
+  const float ry = y > 0.0f ? -t + kTpi : -t - kTpi;
+  const float r0 = y > 0.0f ? kTpi : (y < 0.0f ? -kTpi : 0.0f);  // x == 0
+  return x != 0.0f ? (xg ? rx : ry) : r0;
+}
+__device__ __forceinline__ void sam_chain(float *zs, const float *T, float *ms, CoefPtr cf0, bool store) {
+#pragma clang fp contract(off)
+  const float kTpi = 6.283185307179586476925286766559f;
+  const CoefPtr c = fresh_coef(cf0);
+  const float omega_min = c->sc[kScSamWmin], omega_max = c->sc[kScSamWmax], g1 = c->sc[kScSamG1], g2 = c->sc[kScSamG2];
+  float phzerror = ms[kMiscSamPhz], fil_out = ms[kMiscSamFil], omega2 = ms[kMiscSamOmega];
+  cf zn = *reinterpret_cast<const cf *>(zs);
+  for (int i = 0; i < 256; ++i) {
+    const cf z = zn;
+    if (i < 255) zn = *reinterpret_cast<const cf *>(zs + 2 * i + 2);  // ahead of the dependent chain
+    const float Sin = sam_fast_sine(phzerror * 0.159154943092f, T);
+    const float Cos = sam_fast_sine(phzerror * 0.159154943092f + 0.25f, T);
+    const float ai = Cos * z.x, bi = Sin * z.x, aq = Cos * z.y, bq = Sin * z.y;
+    const float corr0 = +ai + bq, corr1 = -bi + aq;
+    const float audio = (ai - bi) + (aq + bq);
+    zs[2 * i] = audio;
+    const float det = sam_atan2(corr1, corr0);
+    const float del_out = fil_out;
+    omega2 = omega2 + g2 * det;
+    if (omega2 < omega_min) omega2 = omega_min;
+    else if (omega2 > omega_max) omega2 = omega_max;
+    fil_out = g1 * det + omega2;
+    phzerror = phzerror + del_out;
+    // (the source's two `while` loops: |del_out| <= g1 (2 pi + pi / 4) + omega_max < 1.2, so one pass each)
+    if (phzerror >= kTpi) phzerror -= kTpi;
+    if (phzerror < 0.0f) phzerror += kTpi;
+  }
+  if (store) {
+    ms[kMiscSamPhz] = phzerror;
+    ms[kMiscSamFil] = fil_out;
+    ms[kMiscSamOmega] = omega2;
+  }
+}
+
 template <typename AL>
 __device__ __forceinline__ void agc_chain(float *sl, CoefPtr cf0, int lane STAMP_PARAMS) {
   constexpr int kAgR = AL::R, kAgS = AL::S;
@@ -968,7 +1037,10 @@ __device__ __forceinline__ void agc_apply(const cf (&v)[8], float4 agst, float *
   STAMP(23);  // AGC: gain from volts, scaling, record store
 }
 
-constexpr int kModeSsb = 0, kModeAm = 1, kModeNfm = 2;  // kernel template MODE
+constexpr int kModeSsb = 0, kModeAm = 1, kModeNfm = 2, kModeSam = 3;  // kernel template MODE
+// the 4-wave geometry (Geo's second parameter): AGC on, and the synchronous detector, whose PLL is a serial
+// chain run by one wave per workgroup like the AGC's
+constexpr bool geo4(int mode, bool agc) { return agc || mode == kModeSam; }
 
 // ------------------------------------------------------------------------------------------
 // The fused kernel, FFT_LENGTH = 512
@@ -1043,9 +1115,9 @@ static_assert(!Geo<0>::kResident || (Geo<0>::kH1 + 24 <= Geo<0>::kSlice && Geo<0
 // state is written by the wave that READ it (the one that starts the call), from the call's last
 // samples in the same way: a wave of a later run may execute before that one has started.
 template <int MODE, bool DEBUG, int PART, bool PLAIN, bool AGC = false, bool WQ15 = false, bool SEGPAR = false>
-__global__ __launch_bounds__((Geo<PART, AGC>::kWaves * 64), 4) void rx512_kernel(const RxArgs a) {
+__global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC)>::kWaves * 64), 4) void rx512_kernel(const RxArgs a) {
   static_assert(!SEGPAR || (PART == 1 && MODE != kModeNfm) || (PART == 2 && MODE == kModeSsb && !AGC), "SEGPAR variants");
-  typedef Geo<PART, AGC> G;
+  typedef Geo<PART, geo4(MODE, AGC)> G;
   constexpr bool KEEP = G::kResident;  // streaming state stays on chip across the frames of a launch
   constexpr int NW = G::kWaves;
   constexpr int kX = G::kX, kY1 = G::kY1, kScr = G::kScr, kI1 = G::kI1;
@@ -1083,6 +1155,13 @@ __global__ __launch_bounds__((Geo<PART, AGC>::kWaves * 64), 4) void rx512_kernel
       else if (threadIdx.x >= 256 && threadIdx.x < 256 + 56)
         reinterpret_cast<float2 *>(smem)[G::kTw2 + threadIdx.x - 256] =
             a.tab[kTabTw2 + 64 * ((threadIdx.x - 256) >> 3) + ((threadIdx.x - 256) & 7)];
+    } else if (MODE == kModeSam) {
+      // the mask is read from the L2-resident table (as the resident kernels do); its place holds
+      // arm_sin_f32's 513-entry table for the PLL's per-lane look-ups
+      for (int i = threadIdx.x; i < 516; i += 256) smem[i] = reinterpret_cast<const float *>(a.tab + kTabSam)[i];
+      for (int i = 512 / 2 + threadIdx.x; i < (512 + 448) / 2; i += 256) dst[i] = src[i];  // tw1
+      if (threadIdx.x < 56)
+        reinterpret_cast<float2 *>(smem)[kLdsTabTw2 + threadIdx.x] = a.tab[kTabTw2 + 64 * (threadIdx.x >> 3) + (threadIdx.x & 7)];
     } else {
       for (int i = threadIdx.x; i < (512 + 448) / 2; i += 256) dst[i] = src[i];  // mask, tw1
       if (threadIdx.x < 56)  // tw2[q][l1] = table entry [q][lane = l1]
@@ -1194,7 +1273,7 @@ __global__ __launch_bounds__((Geo<PART, AGC>::kWaves * 64), 4) void rx512_kernel
     const float *__restrict__ gQ = a.Q + (WQ15 ? fbase / 2 : fbase);
     float *__restrict__ gO = a.out + (WQ15 ? fbase / 2 : fbase);
 
-    constexpr bool CONTIG = (MODE == kModeAm) || AGC;  // aud[j] = sample 4 lane + j instead of lane + 64 j
+    constexpr bool CONTIG = (MODE == kModeAm) || (AGC && MODE != kModeSam);  // aud[j] = sample 4 lane + j instead of lane + 64 j
     float aud[4];                            // 4 demodulated samples @24 kS/s
     float4 agst = make_float4(0, 0, 0, 0);   // AGC record (delay line + state words), one float4 per lane
     float4 hist1 = make_float4(0, 0, 0, 0);  // x2 interpolator history (lanes 0..5)
@@ -1899,7 +1978,7 @@ __global__ __launch_bounds__((Geo<PART, AGC>::kWaves * 64), 4) void rx512_kernel
       {
         cf tw1[7], tw2[7];
         cf mk[8];  // KEEP: FIR_filter_mask[lane + 64 r] / N, requested from the L2-resident table inside the forward FFT
-        constexpr bool GMASK = KEEP;  // (on the 4-wave geometry, measured: +1.2 .. 2.5 % against mask and twiddles in LDS / registers)
+        constexpr bool GMASK = KEEP || MODE == kModeSam;  // (on the 4-wave geometry, measured: +1.2 .. 2.5 % against mask and twiddles in LDS / registers)
         if (!GMASK) {
   #pragma unroll
           for (int q = 0; q < 7; ++q) {
@@ -1972,7 +2051,32 @@ __global__ __launch_bounds__((Geo<PART, AGC>::kWaves * 64), 4) void rx512_kernel
         agc_apply<AgcLds<KEEP>, NW, G::kSlice>(v, agst, lds, smem + G::kTab, st + st_agc(512 * seg), cf0, lane, wv,
                                                left < NW ? left : NW, og STAMP_ARGS);
       }
-      if (MODE != kModeAm) {
+      if (MODE == kModeSam) {
+        // ---- synchronous AM, AMDecodeSAM() Demod.cpp:40-139: a PLL, one sample at a time.  Every wave
+        // puts its channel's 256 complex samples in its slice in time order; wave 0 then runs the
+        // loops of the workgroup's channels, one lane per channel (all lanes enabled, as in
+        // agc_apply), and leaves the audio in place of the real parts.
+        const int left = a.nchan - NW * (int)blockIdx.x;
+        const int nvalid = left < NW ? left : NW;
+        wave_sync();
+  #pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const cf g = AGC ? og[j] : v[4 + j] * splat(fixed_gain);
+          *reinterpret_cast<cf *>(lds + 2 * (AGC ? 4 * lane + j : lane + 64 * j)) = g;
+        }
+        __syncthreads();
+        if (wv == 0) {
+          PRIO(3);  // the frame's critical path, one dependent instruction at a time
+          const int c = (nvalid == NW) ? (lane & (NW - 1)) : lane % nvalid;
+          sam_chain(smem + G::kTab + c * G::kSlice, smem, a.state + (size_t)(NW * (int)blockIdx.x + c) * state_stride + kStMisc,
+                    cf0, lane < nvalid);
+          PRIO(1);
+        }
+        __syncthreads();
+  #pragma unroll
+        for (int j = 0; j < 4; ++j) aud[j] = lds[2 * (lane + 64 * j)];
+        wave_sync();
+      } else if (MODE != kModeAm) {
   #pragma unroll
         for (int j = 0; j < 4; ++j) aud[j] = AGC ? og[j].x : fixed_gain * v[4 + j].x;
       } else {
@@ -3006,6 +3110,18 @@ hipError_t launch_rx(const RxArgs &a, int fft_length, int mode, hipStream_t s) {
       return launch512<kModeAm>(a, s, debug);
     case T41RX_DEMOD_NFM:
       return launch512<kModeNfm>(a, s, debug);
+    case T41RX_DEMOD_SAM: {  // f32 samples only (refused by the host otherwise); the general front end
+      const int grid = (a.nchan + 3) / 4;
+      if (a.agc) {
+        if (debug) hipLaunchKernelGGL((rx512_kernel<kModeSam, true, 0, false, true, false>), dim3(grid), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((rx512_kernel<kModeSam, false, 0, false, true, false>), dim3(grid), dim3(256), 0, s, a);
+      } else if (debug) {
+        hipLaunchKernelGGL((rx512_kernel<kModeSam, true, 0, false, false, false>), dim3(grid), dim3(256), 0, s, a);
+      } else {
+        hipLaunchKernelGGL((rx512_kernel<kModeSam, false, 0, false, false, false>), dim3(grid), dim3(256), 0, s, a);
+      }
+      return hipGetLastError();
+    }
     default:
       return hipErrorInvalidValue;
   }

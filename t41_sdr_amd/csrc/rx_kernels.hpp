@@ -23,7 +23,9 @@ constexpr int kTabHp4 = kTabHp8 + 64;
 //                   (2 float2), and the biquad's transition-matrix powers (M^4)^((l&15)+1),
 //                   (M^4)^((l&31)+1) as 2 x 2 float2 each
 constexpr int kTabAm = kTabHp4 + 64;
-constexpr int kTabEntries512 = kTabAm + 64 * 6;
+//   sam[260]      : arm_sin_f32's table, 513 floats sin(2 pi k / 512) (+ padding), for the synchronous detector
+constexpr int kTabSam = kTabAm + 64 * 6;
+constexpr int kTabEntries512 = kTabSam + 260;
 
 struct RxArgs {
   const float *__restrict__ I;

@@ -13,7 +13,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import DEMOD_AM, DEMOD_LSB, DEMOD_NFM, DEMOD_USB, Params, T41RxError, check  # noqa: F401
+from ._lib import DEMOD_AM, DEMOD_LSB, DEMOD_NFM, DEMOD_SAM, DEMOD_USB, Params, T41RxError, check  # noqa: F401
 
 
 def default_params(**overrides):
@@ -57,7 +57,7 @@ def blob_fields(blob, fft_length):
     o = BLOB_HEADER_WORDS
     out = {}
     for name, n in (("dec1", 28), ("dec2", 46), ("int1", 48), ("int2", 32), ("biquad_lowpass1", 5),
-                    ("scalars", 11), ("agc", 16), ("mask", 2 * fft_length)):
+                    ("scalars", 16), ("agc", 16), ("mask", 2 * fft_length)):
         out[name] = f[o:o + n]
         o += n
     return out

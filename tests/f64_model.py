@@ -106,6 +106,54 @@ def mask_taps(coeffs, N):
     return h  # length N; taps beyond N/2 are ~0
 
 
+def fast_sin(x, quarter=0.0):
+    """arm_sin_f32 / arm_cos_f32's method in float64: 512-entry table (exact sines), linear interpolation"""
+    t = x * (1.0 / (2.0 * np.pi)) + quarter
+    t = t - np.floor(t)
+    fi = 512.0 * t
+    k = int(fi)
+    fr = fi - k
+    return (1.0 - fr) * np.sin(2.0 * np.pi * k / 512.0) + fr * np.sin(2.0 * np.pi * (k + 1) / 512.0)
+
+
+def approx_atan2(y, x):
+    """Demod.cpp:148-197 as written (2 pi where pi/2 is meant)"""
+    at = lambda z: (0.97239411 + (-0.19194795) * z * z) * z
+    if x != 0.0:
+        if abs(x) > abs(y):
+            z = y / x
+            return at(z) if x > 0.0 else (at(z) + np.pi if y >= 0.0 else at(z) - np.pi)
+        z = x / y
+        return -at(z) + 2.0 * np.pi if y > 0.0 else -at(z) - 2.0 * np.pi
+    return 2.0 * np.pi if y > 0.0 else (-2.0 * np.pi if y < 0.0 else 0.0)
+
+
+def sam_pll(y):
+    """AMDecodeSAM's loop over a whole stream in float64: table-interpolated sine / cosine, the phase detector
+    with ApproxAtan2 as written, the fade leveler with its time constants degenerate (no effect), the PLL
+    constants of Demod.cpp:13-18 with omegaN = 200, pll_fmax = 4000, zeta = 0.65"""
+    omegaN, fmax, zeta = 200.0, 4000.0, 0.65
+    wmin, wmax = -2.0 * np.pi * fmax / 24000.0, 2.0 * np.pi * fmax / 24000.0
+    g1 = 1.0 - np.exp(-2.0 * omegaN * zeta / 24000.0)
+    g2 = -g1 + 2.0 * (1.0 - np.exp(-omegaN * zeta / 24000.0) * np.cos(omegaN / 24000.0 * np.sqrt(1.0 - zeta * zeta)))
+    ph = fil = om = 0.0
+    out = np.empty(y.size)
+    for i in range(y.size):
+        s, c = fast_sin(ph), fast_sin(ph, 0.25)
+        ai, bi, aq, bq = c * y[i].real, s * y[i].real, c * y[i].imag, s * y[i].imag
+        out[i] = (ai - bi) + (aq + bq)
+        det = approx_atan2(-bi + aq, ai + bq)
+        dl = fil
+        om = min(max(om + g2 * det, wmin), wmax)
+        fil = g1 * det + om
+        ph = ph + dl
+        while ph >= 2.0 * np.pi:
+            ph -= 2.0 * np.pi
+        while ph < 0.0:
+            ph += 2.0 * np.pi
+    return out
+
+
 def run(I, Q, nco_freq, coeffs, *, fft_length=512, mode=0, FLoCut=200, FHiCut=3000,
         rfGainAllBands=1, RFgain=1, iq_amp=1.0, iq_phase=0.0, audioVolume=30,
         xmtMode=0, CWFreqShift=750, agc=None, agc_trace=None):
@@ -140,7 +188,7 @@ def run(I, Q, nco_freq, coeffs, *, fft_length=512, mode=0, FLoCut=200, FHiCut=30
 
     I = I * float(RFgain)
     Q = Q * float(RFgain)
-    if mode in (0, 1, 2):
+    if mode in (0, 1, 2, 8):
         I = I * (-float(np.float32(iq_amp)))
         ph = float(np.float32(iq_phase))
         if ph < 0.0:
@@ -198,6 +246,8 @@ def run(I, Q, nco_freq, coeffs, *, fft_length=512, mode=0, FLoCut=200, FHiCut=30
         y = gain(np.convolve(z, h)[:z.size])
         if mode in (0, 1):
             aud = y.real.copy()
+        elif mode == 8:  # SAM (Demod.cpp:40-139 as written, see sam_pll)
+            aud = sam_pll(y)
         else:  # AM
             m = _alpha_beta_mag(y.real, y.imag)
             w = signal.lfilter([1.0, -1.0], [1.0, -float(np.float32(0.99))], m)

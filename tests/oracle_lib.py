@@ -13,6 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 
 DEMOD_USB, DEMOD_LSB, DEMOD_AM, DEMOD_NFM = 0, 1, 2, 3
+DEMOD_SAM = 8
 (TAP_POST_NCO_I, TAP_POST_NCO_Q, TAP_DEC_I, TAP_DEC_Q, TAP_IFFT, TAP_DEMOD, TAP_AGC_VOLTS, TAP_AUDIO_SPECT, TAP_AUDIO_MAX,
  TAP_AGC_EDGES, TAP_FFT_SPEC, TAP_FFT_SPEC_OLD) = range(12)
 AGC_NAMES = ("attack_mult", "decay_mult", "fast_decay_mult", "fast_backmult", "onemfast_backmult",

@@ -88,3 +88,23 @@ def fade(I, Q, segments):
     e = envelope_steps(I.shape[-1], segments)
     return (np.clip(I * e, -0.999, 0.999).astype(np.float32),
             np.clip(Q * e, -0.999, 0.999).astype(np.float32))
+
+
+def make_am_carrier(n_channels, n_samples, nco_hz, seed=0x53414D, noise=0.003, offset_hz=(-120.0, 120.0)):
+    """AM carriers for the synchronous detector (SAM): one per channel, landing `offset_hz` away from
+    0 Hz after the I flip, +Fs/4 and -NCO (inside the PLL's +-4 kHz range), sinusoidal modulation
+    300..2500 Hz with depth 0.3..0.8, random start phase"""
+    nco_hz = np.broadcast_to(np.asarray(nco_hz, dtype=np.float64), (n_channels,))
+    I = np.empty((n_channels, n_samples), dtype=np.float32)
+    Q = np.empty((n_channels, n_samples), dtype=np.float32)
+    n = np.arange(n_samples, dtype=np.float64)
+    for c in range(n_channels):
+        rng = np.random.default_rng(seed + c)
+        fm, depth, amp = rng.uniform(300, 2500), rng.uniform(0.3, 0.8), rng.uniform(0.1, 0.4)
+        fc = passband_tone_hz(2, nco_hz[c], rng.uniform(*offset_hz))
+        env = amp * (1.0 + depth * np.sin(2 * np.pi * fm / FS * n + rng.uniform(0, 6.28)))
+        x = env * np.exp(1j * (2 * np.pi * fc / FS * n + rng.uniform(0, 6.28)))
+        x += noise * (rng.standard_normal(n_samples) + 1j * rng.standard_normal(n_samples))
+        I[c] = np.clip(x.real, -0.999, 0.999)
+        Q[c] = np.clip(x.imag, -0.999, 0.999)
+    return I, Q

@@ -5,7 +5,7 @@
 # copies the summaries into profiles/ and rewrites profiles/hbm_traffic.json.
 # usage: tools/profile_round.sh TAG [workload ...]
 TAG=$1; shift
-WL=${@:-ssb nfm nfm_atan am ssb_agc ssb_q15 fft4096}
+WL=${@:-ssb nfm nfm_atan am sam ssb_agc ssb_q15 fft4096}
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/profile_$TAG
 mkdir -p $OUT

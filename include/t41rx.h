@@ -60,7 +60,7 @@ extern "C" {
 /* The firmware globals ProcessIQData() reads, gathered into one POD (SURVEY 8b "Parameters"). */
 typedef struct t41rx_params {
   int32_t fft_length;              /* FFT_LENGTH, SDT.h:39. 512 = reference; see t41rx_supported_fft_length */
-  int32_t mode;                    /* bands[currentBand].mode */
+  int32_t mode;                    /* bands[currentBand].mode: T41RX_DEMOD_USB / LSB / AM / NFM / SAM (SDT.h:58-68) */
   int32_t FLoCut;                  /* bands[currentBand].FLoCut [Hz], SDT.h:186 */
   int32_t FHiCut;                  /* bands[currentBand].FHiCut [Hz], SDT.h:185 */
   int32_t rfGainAllBands;          /* gwv.cpp:17, Process.cpp:117 */

@@ -12,9 +12,9 @@ mkdir -p $OUT
 cd /tmp
 for W in $WL; do
   echo "== $W"
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$W/trace -o t -- python3 $GRAFT_REPO_ROOT/bench.py --workload $W --steps 30 --warmup 5 --no-cpu-baseline > $OUT/$W.trace.log 2>&1 || echo "trace $W failed"
+  timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$W/trace -o t -- python3 $GRAFT_REPO_ROOT/bench.py --workload $W --steps 30 --warmup 5 --no-cpu-baseline > $OUT/$W.trace.log 2>&1 || echo "trace $W failed"
   for C in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $C --output-format csv -d $OUT/$W/$C -o p -- python3 $GRAFT_REPO_ROOT/bench.py --workload $W --steps 6 --warmup 2 --no-cpu-baseline > $OUT/$W.$C.log 2>&1 || echo "pmc $C $W failed"
+    timeout -k 10 240 rocprofv3 --pmc $C --output-format csv -d $OUT/$W/$C -o p -- python3 $GRAFT_REPO_ROOT/bench.py --workload $W --steps 6 --warmup 2 --no-cpu-baseline > $OUT/$W.$C.log 2>&1 || echo "pmc $C $W failed"
   done
   tail -1 $OUT/$W.trace.log | cut -c1-200
 done
@@ -27,7 +27,7 @@ PASSES=(
 i=0
 for CNT in "${PASSES[@]}"; do
   i=$((i+1))
-  rocprofv3 --pmc $CNT --output-format csv -d $OUT/ssb/sq$i -o p -- python3 $GRAFT_REPO_ROOT/bench.py --workload ssb --steps 6 --warmup 2 --no-cpu-baseline > $OUT/ssb.sq$i.log 2>&1 || echo "sq pass $i failed"
+  timeout -k 10 240 rocprofv3 --pmc $CNT --output-format csv -d $OUT/ssb/sq$i -o p -- python3 $GRAFT_REPO_ROOT/bench.py --workload ssb --steps 6 --warmup 2 --no-cpu-baseline > $OUT/ssb.sq$i.log 2>&1 || echo "sq pass $i failed"
 done
 # keep the merge small: per-dispatch traces are not needed, and of the counter CSVs only our kernels' rows
 find $OUT -name "*kernel_trace.csv" -delete

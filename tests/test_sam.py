@@ -153,3 +153,31 @@ def test_gpu_sam_refusals(built):
     with pytest.raises(T.T41RxError) as e:
         rx.ProcessIQData_q15(z, z)
     assert e.value.status == _lib.ERR_UNSUPPORTED
+
+
+@pytest.mark.gpu
+def test_gpu_sam_side_outputs(built):
+    """the tap kernels exist for the mode too: the audio spectrum / S-meter by-product (Process.cpp:550-570,
+    taken in front of the detector, so comparable from the first frame on) and the post-decimation tap"""
+    import torch
+    import t41_sdr_amd as T
+    nch, nfr = 5, 2
+    nco = siggen.nco_grid(nch, seed=31)
+    I, Q = siggen.make_am_carrier(nch, nfr * L, nco, seed=9)
+    rx = T.RxChain(nch, T.default_params(**KW), NCOFreq=nco)
+    sp = torch.zeros(nch, nfr, 1024, device="cuda")
+    mx = torch.zeros(nch, nfr, 3, device="cuda")
+    dec = torch.zeros(nch, nfr * 512, device="cuda")
+    rx.set_audio_spectrum(sp, mx)
+    rx.set_debug_taps(None, dec, None)
+    rx.ProcessIQData(torch.from_numpy(I).cuda(), torch.from_numpy(Q).cuda())
+    sp, dec = sp.cpu().numpy(), dec.cpu().numpy()
+    ob = O.OracleBatch(O.default_params(**KW), np.asarray(nco, np.int32))
+    for f in range(nfr):
+        ob.process(np.ascontiguousarray(I[:, f * L:(f + 1) * L]), np.ascontiguousarray(Q[:, f * L:(f + 1) * L]))
+        for c in range(nch):
+            rs = ob.tap(c, O.TAP_AUDIO_SPECT, 1024)
+            assert np.abs(sp[c, f] - rs).max() <= 3e-5 * rs.max()
+            ri, rq = ob.tap(c, O.TAP_DEC_I, 256), ob.tap(c, O.TAP_DEC_Q, 256)
+            g = dec[c, f * 512:(f + 1) * 512]
+            assert max(np.abs(g[:256] - ri).max(), np.abs(g[256:] - rq).max()) <= 1e-5 * max(np.abs(ri).max(), np.abs(rq).max())

@@ -101,7 +101,7 @@ void t41rx_default_params(t41rx_params *p);
  *   header (24 x int32: magic, abi, fft_length, mode, sizeof(t41rx_params), 3 reserved, then the
  *   t41rx_params the blob was designed for, padded to 16 words) |
  *   FIR_dec1_coeffs[28] | FIR_dec2_coeffs[46] | FIR_int1_coeffs[48] | FIR_int2_coeffs[32] |
- *   biquad_lowpass1_coeffs[5] | scalars[11] | AGC constants[16] (what AGCPrep() +
+ *   biquad_lowpass1_coeffs[5] | scalars[16] (gains, level adjust, volume, the SAM PLL constants) | AGC constants[16] (what AGCPrep() +
  *   AGCLoadValues() leave behind, DSP_Fn.cpp:368-468; zeros for AGCMode 0) |
  *   FIR_filter_mask[2*fft_length]                                                (all f32)
  * This blob is what rank 0 broadcasts over RCCL after a filter change. */

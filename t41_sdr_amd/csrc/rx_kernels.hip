@@ -815,7 +815,10 @@ __device__ __forceinline__ lanemask agc_fast_block(AgcState &st, AgcLane &d, con
 // As written there: the fade leveler's time constants are exp(-1 / 24000 * tau) = exp(0) = 1 (integer
 // division), so it adds dc_insert - dc = 0 to the audio; ApproxAtan2 returns +-2 pi where +-pi/2 is
 // meant.  arm_sin_f32 / arm_cos_f32: 512-entry table, linear interpolation (CMSIS-DSP >= 1.4.5).
-__device__ __forceinline__ float sam_fast_sine(float in, const float *T) {
+// (index, fract) first and the table reads of sine and cosine together: the two evaluations are
+// independent, and the loop is one dependent instruction after another
+struct SamIdx { unsigned index; float fract; };
+__device__ __forceinline__ SamIdx sam_table_index(float in) {
 #pragma clang fp contract(off)
   int n = (int)in;
   if (in < 0.0f) n--;
@@ -826,9 +829,7 @@ __device__ __forceinline__ float sam_fast_sine(float in, const float *T) {
     index = 0;
     findex -= 512.0f;
   }
-  const float fract = findex - (float)index;
-  const float a = T[index], b = T[index + 1];
-  return (1.0f - fract) * a + fract * b;
+  return SamIdx{index, findex - (float)index};
 }
 __device__ __forceinline__ float sam_atan(float z) {  // ApproxAtan, Utility.cpp:298-302
 #pragma clang fp contract(off)
@@ -855,8 +856,10 @@ __device__ __forceinline__ void sam_chain(float *zs, const float *T, float *ms, 
   for (int i = 0; i < 256; ++i) {
     const cf z = zn;
     if (i < 255) zn = *reinterpret_cast<const cf *>(zs + 2 * i + 2);  // ahead of the dependent chain
-    const float Sin = sam_fast_sine(phzerror * 0.159154943092f, T);
-    const float Cos = sam_fast_sine(phzerror * 0.159154943092f + 0.25f, T);
+    const SamIdx is = sam_table_index(phzerror * 0.159154943092f), ic = sam_table_index(phzerror * 0.159154943092f + 0.25f);
+    const float sa = T[is.index], sb = T[is.index + 1], ca = T[ic.index], cb = T[ic.index + 1];
+    const float Sin = (1.0f - is.fract) * sa + is.fract * sb;
+    const float Cos = (1.0f - ic.fract) * ca + ic.fract * cb;
     const float ai = Cos * z.x, bi = Sin * z.x, aq = Cos * z.y, bq = Sin * z.y;
     const float corr0 = +ai + bq, corr1 = -bi + aq;
     const float audio = (ai - bi) + (aq + bq);

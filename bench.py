@@ -62,7 +62,7 @@ WORKLOADS = {
     "ssb_q15": dict(batch=4096, fft=512, kw=dict(mode=0, FLoCut=200, FHiCut=3000), q15=True,
                     name="configs[1] on the firmware's own sample format either side (q15 record-queue blocks in, "
                          "arm_float_to_q15 out; Process.cpp:102-111, 936): 6 B per input complex sample (SURVEY 8f rank 3)"),
-    "fft4096": dict(batch=1024, fft=4096, kw=dict(mode=0, FLoCut=400, FHiCut=600), frames=16,
+    "fft4096": dict(batch=1024, fft=4096, kw=dict(mode=0, FLoCut=400, FHiCut=600), frames=32,
                     name="configs[3]: PSK31-like narrow USB filter, 4096-pt fast-conv (synthetic generalisation), "
                          "1024 channels x 16384 samples per frame"),
 }
@@ -173,7 +173,11 @@ def synth_ring(torch, n_channels, nco_hz, ring, frames, frame_len, device, seed,
         freqs[:, 0] = -48000.0 + nco
         amps[:, 0] = 0.3
     Is, Qs = [], []
-    chunk = 2048
+    # a few large chunks rather than many small ones: fewer dispatches (rocprofv3 --pmc has segfaulted inside torch's
+    # element-wise launches when a profiled run made tens of thousands of them), ~256 MiB per float64 temporary
+    chunk = frame_len
+    while 2 * chunk * n_channels <= (1 << 25) and (frames * frame_len) % (2 * chunk) == 0:
+        chunk *= 2
     for r in range(ring):
         bI = torch.empty(n_channels, frames * frame_len, device=device, dtype=torch.float32)
         bQ = torch.empty_like(bI)

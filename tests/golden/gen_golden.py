@@ -4,7 +4,7 @@ The reference ships no golden vectors for this path, and cannot r
 these fixtures pin the ORACLE's behaviour (oracle/t41_oracle.c at the commit that generated
 them): they catch regressions of the oracle and give the GPU tests data that does not depend
 on rebuilding anything.  Re-run only when the oracle's semantics change on purpose:
-    python tests/golden/gen_golden.py
+    python tests/golden/gen_golden.py [case ...]
 """
 import os
 import sys
@@ -36,9 +36,12 @@ CASES = {
     # side output (Process.cpp:550-570) and the q15 boundary (Process.cpp:102-111, 936): extra arrays, see main()
     "usb_spectrum": (dict(mode=0, FLoCut=200, FHiCut=3000), [5000, -12350]),
     "usb_q15": (dict(mode=0, FLoCut=200, FHiCut=3000, audioVolume=100), [5000, -12350]),
+    # synchronous AM (Demod.cpp:40-139): long enough for the PLL to lock (tests compare the GPU from frame 12 on)
+    "sam": (dict(mode=8, FLoCut=-3000, FHiCut=3000), [1000, -20000]),
 }
 FADE = [(0.3, 2.0), (0.3, 0.05), (0.4, 1.2)]  # AGC cases
 NFRAMES_AGC = 10
+NFRAMES_SAM = 14
 NFRAMES = 3
 L = 2048
 
@@ -54,6 +57,8 @@ def make_inputs(name, kw, nco):
         return siggen.fade(I, Q, FADE)
     nch = len(nco)
     seed = 0x5441315F + sum(ord(c) for c in name)
+    if kw["mode"] == 8:
+        return siggen.make_am_carrier(nch, NFRAMES_SAM * L, np.asarray(nco), seed=seed)
     if kw["mode"] == 3:  # FM-modulated carriers so the discriminator sees a real signal
         rng = np.random.default_rng(seed)
         n = np.arange(NFRAMES * L)
@@ -72,7 +77,10 @@ def make_inputs(name, kw, nco):
 
 
 def main():
+    only = set(sys.argv[1:])  # optional: the cases to (re)generate
     for name, (kw, nco) in CASES.items():
+        if only and name not in only:
+            continue
         I, Q = make_inputs(name, kw, nco)
         p = O.default_params(**kw)
         ob = O.OracleBatch(p, np.asarray(nco, dtype=np.int32))

@@ -326,7 +326,8 @@ int design_blob(const t41rx_params &p, void *blob, size_t blob_bytes) {
     s[kScSamWmax] = TPI * pll_fmax * 1 / 24000;
     const float g1 = 1.0 - std::exp(-2.0 * omegaN * zeta * 1 / 24000);
     s[kScSamG1] = g1;
-    s[kScSamG2] = -g1 + 2.0 * (1 - std::exp(-omegaN * zeta * 1 / 24000) * cosf(omegaN * 1 / 24000 * sqrtf(1.0 - zeta * zeta)));
+    // (exp() of the float argument evaluates in double, like cos(NCO_INC) in FreqShift2: DESIGN.md section 2)
+    s[kScSamG2] = -g1 + 2.0 * (1 - std::exp((double)(-omegaN * zeta * 1 / 24000)) * cosf(omegaN * 1 / 24000 * sqrtf(1.0 - zeta * zeta)));
   }
   return T41RX_OK;
 }

@@ -181,3 +181,20 @@ def test_gpu_sam_side_outputs(built):
             ri, rq = ob.tap(c, O.TAP_DEC_I, 256), ob.tap(c, O.TAP_DEC_Q, 256)
             g = dec[c, f * 512:(f + 1) * 512]
             assert max(np.abs(g[:256] - ri).max(), np.abs(g[256:] - rq).max()) <= 1e-5 * max(np.abs(ri).max(), np.abs(rq).max())
+
+
+def test_designer_carries_the_pll_constants_bit_for_bit(built):
+    """host-side designer (no GPU needed): the blob's SAM scalars are the oracle's constants exactly, and the
+    mode is refused at the long FFT lengths"""
+    import t41_sdr_amd as T
+    from t41_sdr_amd import _lib as tlib
+    want = (C.c_float * 4)()
+    _lib().t41o_sam_constants(want)
+    s = T.blob_fields(T.design_coeffs(T.default_params(**KW)), 512)["scalars"]
+    assert np.array_equal(np.asarray(s[10:14], np.float32), np.asarray(list(want), np.float32))
+    assert s[7] == 1.0  # IQ correction applies in SAM (Process.cpp:165-169)
+    with pytest.raises(T.T41RxError) as e:
+        T.design_coeffs(T.default_params(**dict(KW, fft_length=1024)))
+    assert e.value.status == tlib.ERR_ARG
+    p = T.blob_params(T.design_coeffs(T.default_params(**KW)))
+    assert p.mode == T.DEMOD_SAM == 8

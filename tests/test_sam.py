@@ -198,3 +198,27 @@ def test_designer_carries_the_pll_constants_bit_for_bit(built):
     assert e.value.status == tlib.ERR_ARG
     p = T.blob_params(T.design_coeffs(T.default_params(**KW)))
     assert p.mode == T.DEMOD_SAM == 8
+
+
+@pytest.mark.gpu
+def test_gpu_switch_to_sam_mid_stream(built):
+    """SetupMode() from USB to SAM between two calls: another kernel geometry takes over the same channel records
+    (delay lines, oscillator, overlap block); the PLL starts from rest and is compared once locked"""
+    import torch
+    import t41_sdr_amd as T
+    nch, n0, n1 = 5, 2, 14
+    nco = siggen.nco_grid(nch, seed=41)
+    I, Q = siggen.make_am_carrier(nch, (n0 + n1) * L, nco, seed=11)
+    rx = T.RxChain(nch, T.default_params(mode=0, FLoCut=200, FHiCut=3000), NCOFreq=nco)
+    x, y = torch.from_numpy(I).cuda(), torch.from_numpy(Q).cuda()
+    a = rx.ProcessIQData(x[:, :n0 * L].contiguous(), y[:, :n0 * L].contiguous()).cpu().numpy()
+    rx.SetupMode(**KW)
+    b = rx.ProcessIQData(x[:, n0 * L:].contiguous(), y[:, n0 * L:].contiguous()).cpu().numpy()
+    ob = O.OracleBatch(O.default_params(mode=0, FLoCut=200, FHiCut=3000), np.asarray(nco, np.int32))
+    ra = ob.process(np.ascontiguousarray(I[:, :n0 * L]), np.ascontiguousarray(Q[:, :n0 * L]))
+    for k, v in KW.items():
+        setattr(ob.p, k, v)
+    ob.redesign()
+    rb = ob.process(np.ascontiguousarray(I[:, n0 * L:]), np.ascontiguousarray(Q[:, n0 * L:]))
+    assert siggen.block_rel_err(a, ra, L).max() <= 1e-5
+    assert siggen.block_rel_err(b, rb, L)[:, LOCKED:].max() <= 1e-5

@@ -93,7 +93,7 @@ def load_traffic(workload, frames):
         return None
     if e.get("source_hash") != kernel_source_hash():
         print("note: profiles/hbm_traffic.json[%s] was measured on another kernel source (hash %s, now %s): "
-              "roofline.traffic = null until tools/prof_pmc.sh is re-run" % (workload, e.get("source_hash"), kernel_source_hash()),
+              "roofline.traffic = null until tools/profile_round.sh + tools/collect_profiles.py are re-run" % (workload, e.get("source_hash"), kernel_source_hash()),
               file=sys.stderr)
         return None
     if e.get("frames_per_launch", 1) != frames:
@@ -197,37 +197,67 @@ def synth_ring(torch, n_channels, nco_hz, ring, frames, frame_len, device, seed,
     return Is, Qs
 
 
+def host_cpu():
+    """(model string, logical CPUs the OS reports, CPUs this process may actually use: affinity mask and cgroup quota)"""
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    logical = os.cpu_count() or 1
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else logical
+    try:  # cgroup v2 CPU quota ("max" or "<quota> <period>")
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+        if q != "max":
+            usable = max(1, min(usable, int(float(q) / float(per) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return model, logical, usable
+
+
 def cpu_baseline(torch, Is, Qs, nco_hz, params_kw, n_channels, frame_len):
-    """The CPU oracle (oracle/t41_oracle.c, a port: the reference itself is Teensy firmware)
-    on a bounded sample of the same workload, all host threads."""
+    """The CPU oracle (oracle/t41_oracle.c, a port: the reference itself is Teensy firmware) on a
+    bounded sample of the same workload: >= 1.5 s of wall time with every usable host thread and
+    >= 1.5 s on one thread (BASELINE.md section 3 asks for both and for the CPU model)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
+    model, logical, usable = host_cpu()
+    threads = max(1, min(usable, 64))
     nch = min(1024, n_channels)
     nfr = min(8, Is[0].shape[1] // frame_len)
-    passes = 6
-    threads = max(1, min(os.cpu_count() or 1, 64))
     I = Is[0][:nch, :nfr * frame_len].cpu().numpy()
     Q = Qs[0][:nch, :nfr * frame_len].cpu().numpy()
-    ob = O.OracleBatch(O.default_params(**params_kw), np.asarray(nco_hz[:nch], dtype=np.int32), native=True)
-    ob.process(I[:, :frame_len], Q[:, :frame_len], nthreads=threads)  # warm caches / twiddle tables
-    t0 = time.perf_counter()
-    for _ in range(passes):
-        ob.process(I, Q, nthreads=threads)
-    dt = time.perf_counter() - t0
-    nsamp = passes * nch * I.shape[1]
-    # single-thread figure on a smaller slice
-    ob1 = O.OracleBatch(O.default_params(**params_kw), np.asarray(nco_hz[:64], dtype=np.int32), native=True)
-    t1 = time.perf_counter()
-    ob1.process(I[:64], Q[:64], nthreads=1)
-    dt1 = time.perf_counter() - t1
+
+    def rate(nchan, nthreads, min_s):
+        ob = O.OracleBatch(O.default_params(**params_kw), np.asarray(nco_hz[:nchan], dtype=np.int32), native=True)
+        ob.process(I[:nchan, :frame_len], Q[:nchan, :frame_len], nthreads=nthreads)  # warm caches / twiddle tables
+        passes, t0 = 0, time.perf_counter()
+        while passes < 3 or time.perf_counter() - t0 < min_s:
+            ob.process(I[:nchan], Q[:nchan], nthreads=nthreads)
+            passes += 1
+        dt = time.perf_counter() - t0
+        ob.close()
+        return passes * nchan * I.shape[1] / dt / 1e6, passes, dt
+
+    v_all, p_all, t_all = rate(nch, threads, 1.5)
+    v_one, p_one, t_one = rate(min(64, nch), 1, 1.5)
     return {
-        "value": round(nsamp / dt / 1e6, 3),
+        "value": round(v_all, 1),
         "unit": "MSamples/s",
         "cores": threads,
         "kind": "port",
-        "sample": "%d of the %d channels x %d consecutive frames, %d passes, oracle/t41_oracle.c -O3 -march=native, "
-                  "one channel range per thread; 1-thread rate on 64 channels x %d frames: %.3f MSamples/s"
-                  % (nch, n_channels, nfr, passes, nfr, 64 * I.shape[1] / dt1 / 1e6),
+        "single_thread_value": round(v_one, 2),
+        "host_cpu": model,
+        "host_logical_cpus": logical,
+        "host_usable_cpus": usable,
+        "sample": "oracle/t41_oracle.c -O3 -march=native on %d of the %d channels x %d consecutive frames, one channel range per "
+                  "thread: %d passes in %.2f s on %d threads; 1 thread: %d channels, %d passes in %.2f s"
+                  % (nch, n_channels, nfr, p_all, t_all, threads, min(64, nch), p_one, t_one),
     }
 
 
@@ -257,12 +287,19 @@ def dry_run(args, world, rank):
     if hashlib.sha256(blob.tobytes()).hexdigest() != want:
         raise SystemExit("rank %d: broadcast coefficient blob differs from rank 0's design" % rank)
     wall = 1.0 + rank
+    # the device every rank would select (torch.cuda.set_device(LOCAL_RANK) in the real run): one GPU each
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_ranks = [local_rank]
     if world > 1:
         wall = max_over_ranks(wall)
+        local_ranks = [None] * world
+        dist.all_gather_object(local_ranks, local_rank)
         dist.barrier()
+    if len(set(local_ranks)) != len(local_ranks):
+        raise SystemExit("two ranks would select the same device: LOCAL_RANK values %r" % (local_ranks,))
     if rank == 0:
         print(json.dumps({"dry_run": True, "n_gpus": observed, "world_size_observed": observed,
-                          "channels": [lo, hi], "wall_max": wall, "coeff_sha256": want[:16]}), flush=True)
+                          "channels": [lo, hi], "wall_max": wall, "coeff_sha256": want[:16], "local_ranks": local_ranks}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
@@ -275,6 +312,7 @@ def main():
     ap.add_argument("--frames-per-launch", type=int, default=0,
                     help="consecutive frames per channel per launch (default %d; 1 = one ProcessIQData() per launch)" % DEFAULT_FRAMES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true", help="skip the nfm / fft4096 / ssb_agc timings behind the headline (N = 1, ssb)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="ssb")
     ap.add_argument("--dry-run", action="store_true", help="CPU-only rehearsal of the multi-rank plumbing (gloo)")
     args = ap.parse_args()
@@ -307,75 +345,13 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    wl = WORKLOADS[args.workload]
-    n_channels = int(os.environ.get("T41RX_BENCH_NCH", wl["batch"]))  # env override: scaling experiments only
-    fft_length = wl["fft"]
-    frame_len = 4 * fft_length
-    frames = args.frames_per_launch or wl.get("frames", DEFAULT_FRAMES)
-    params_kw = dict(fft_length=fft_length, rfGainAllBands=1, RFgain=1, AGCMode=0, audioVolume=30)
-    params_kw.update(wl["kw"])
-    # the global batch is world x n_channels channels; this rank owns a contiguous shard of it
-    lo, hi = shard_channels(world * n_channels, rank, world)
-    rng = np.random.default_rng(1000)
-    nco_all = (rng.integers(-860, 801, world * n_channels) * 50).astype(np.int32)  # [-43000, 40000] Hz, 50 Hz steps
-    nco = nco_all[lo:hi]
-
-    # One-shot coefficient broadcast: rank 0 designs the filters, everyone installs them (RCCL over xGMI).
-    params = T.default_params(**params_kw)
-    rx = T.RxChain(hi - lo, params if rank == 0 else T.default_params(fft_length=fft_length), device=local_rank, NCOFreq=nco)
-    if dist is not None:
-        rx.set_coeffs(broadcast_coeffs(rx.coeffs(), src=0, device=dev))
-    got = rx.get_params()
-    for k, v in params_kw.items():
-        if getattr(got, k) != v:
-            raise SystemExit("rank %d: parameter %s = %r after the coefficient broadcast, expected %r" % (rank, k, getattr(got, k), v))
-
-    # ring: more than the 256 MiB Infinity Cache between two uses of the same buffer
-    bytes_per_buf = 3 * (hi - lo) * frames * frame_len * 4
-    ring = max(2, -(-(768 << 20) // bytes_per_buf))
-    Is, Qs = synth_ring(torch, hi - lo, nco, ring, frames, frame_len, dev, seed=0x5441315F + rank, mode=params.mode)
-    q15 = bool(wl.get("q15"))
-    bytes_per_sample = 6.0 if q15 else BYTES_PER_SAMPLE  # 2 x int16 in + int16 out
-    if q15:  # what the codec would deliver for these waveforms
-        Is = [(x * 32768.0).round_().clamp_(-32768, 32767).to(torch.int16) for x in Is]
-        Qs = [(x * 32768.0).round_().clamp_(-32768, 32767).to(torch.int16) for x in Qs]
-    outs = [torch.empty_like(x) for x in Is]
-
-    def step(k):
-        r = k % ring
-        if q15:
-            rx.ProcessIQData_q15(Qs[r], Is[r], out=outs[r])  # L queue carries Q, R queue carries I
-        else:
-            rx.ProcessIQData(Is[r], Qs[r], out=outs[r])
-
-    for k in range(args.warmup):
-        step(k)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()  # same stream the kernels are enqueued on (torch's current stream)
-    for k in range(args.steps):
-        step(args.warmup + k)
-    ev1.record()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # average launch duration, HIP events
-    if dist is not None:
-        wall = max_over_ranks(wall, device=dev)
-
-    if not q15 and not os.environ.get("T41RX_BENCH_NOCHECK") and not torch.isfinite(outs[(args.warmup + args.steps - 1) % ring]).all():
+    head = Workload(torch, T, args.workload, world, rank, local_rank, dev, dist, args.frames_per_launch)
+    wall, kernel_ms = head.time(args.steps, args.warmup)
+    if not head.q15 and not os.environ.get("T41RX_BENCH_NOCHECK") and not torch.isfinite(head.outs[(args.warmup + args.steps - 1) % head.ring]).all():
         raise SystemExit("non-finite audio output")
 
-    samples_per_step = (hi - lo) * frames * frame_len
-    value = world * samples_per_step * args.steps / wall / 1e6
-    achieved = bytes_per_sample * samples_per_step / (kernel_ms * 1e-3) / 1e9
+    wl = head.wl
+    value = world * head.samples_per_step * args.steps / wall / 1e6
     line = {
         "metric": "MSamples/s I/Q through full RX chain, batch=4096; achieved HBM GB/s vs roofline",
         "value": round(value, 1),
@@ -387,36 +363,204 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32" if not q15 else "f32 (q15 samples in and out)",
+        "dtype": "f32" if not head.q15 else "f32 (q15 samples in and out)",
         "data": "synthetic",
         "config": {
             "workload": wl["name"],
-            "batch": hi - lo, "frame_len": frame_len, "fft_length": fft_length,
-            "frames_per_launch": frames,
+            "batch": head.n, "frame_len": head.frame_len, "fft_length": head.fft_length,
+            "frames_per_launch": head.frames,
             "world_size_observed": observed,
             "parallelism": "channels sharded per GPU (one process per GPU), one-shot RCCL coefficient broadcast, no data-path collective",
         },
-        "roofline": {
+        "roofline": head.roofline(kernel_ms),
+    }
+    if rank == 0:
+        # the timed stream against the CPU oracle, in the timed launch shape (replayed: see parity_check)
+        if not os.environ.get("T41RX_BENCH_NOCHECK"):
+            line["parity_check"] = parity_check(torch, head, min(args.warmup + args.steps, 160), args.warmup + args.steps)
+        if world == 1 and not args.no_cpu_baseline and args.workload == "ssb":
+            line["cpu_baseline"] = cpu_baseline(torch, head.Is, head.Qs, head.nco, head.params_kw, head.n, head.frame_len)
+    head.free()
+    if rank == 0 and world == 1 and args.workload == "ssb" and not args.no_other_workloads:
+        # BASELINE configs[2] / [3] and the firmware's default AGC mode, timed in this same run
+        others = {}
+        for name in ("nfm", "fft4096", "ssb_agc"):
+            w = Workload(torch, T, name, 1, 0, local_rank, dev, None, 0)
+            _, kms = w.time(12, 4)
+            r = w.roofline(kms)
+            entry = {"workload": w.wl["name"], "batch": w.n, "frames_per_launch": w.frames, "kernel_ms": r["kernel_ms"],
+                     "us_per_frame": r["us_per_frame"], "frac": r["frac"], "achieved_GBs": r["achieved"], "traffic": r["traffic"]}
+            if not os.environ.get("T41RX_BENCH_NOCHECK"):
+                entry["parity_check"] = parity_check(torch, w, 2, 16)
+            others[name] = entry
+            w.free()
+        line["other_workloads"] = others
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+        bad = [k for k, v in [("headline", line.get("parity_check"))] + [(n, e.get("parity_check")) for n, e in line.get("other_workloads", {}).items()]
+               if v is not None and not v["ok"]]
+        if bad:
+            raise SystemExit("parity check failed for: %s" % ", ".join(bad))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+class Workload:
+    """One bench workload on this rank: context, synthetic ring of launch buffers, the step."""
+
+    def __init__(self, torch, T, name, world, rank, local_rank, dev, dist, frames_override):
+        from t41_sdr_amd.dist import broadcast_coeffs, shard_channels
+        self.torch, self.dist, self.dev, self.name = torch, dist, dev, name
+        self.wl = wl = WORKLOADS[name]
+        n_channels = int(os.environ.get("T41RX_BENCH_NCH", wl["batch"]))  # env override: scaling experiments only
+        self.fft_length = wl["fft"]
+        self.frame_len = 4 * self.fft_length
+        self.frames = frames_override or wl.get("frames", DEFAULT_FRAMES)
+        self.params_kw = dict(fft_length=self.fft_length, rfGainAllBands=1, RFgain=1, AGCMode=0, audioVolume=30)
+        self.params_kw.update(wl["kw"])
+        # the global batch is world x n_channels channels; this rank owns a contiguous shard of it
+        lo, hi = shard_channels(world * n_channels, rank, world)
+        self.n = hi - lo
+        rng = np.random.default_rng(1000)
+        nco_all = (rng.integers(-860, 801, world * n_channels) * 50).astype(np.int32)  # [-43000, 40000] Hz, 50 Hz steps
+        self.nco = nco_all[lo:hi]
+        # One-shot coefficient broadcast: rank 0 designs the filters, everyone installs them (RCCL over xGMI).
+        params = T.default_params(**self.params_kw)
+        self.rx = T.RxChain(self.n, params if rank == 0 else T.default_params(fft_length=self.fft_length), device=local_rank, NCOFreq=self.nco)
+        if dist is not None:
+            self.rx.set_coeffs(broadcast_coeffs(self.rx.coeffs(), src=0, device=dev))
+        got = self.rx.get_params()
+        for k, v in self.params_kw.items():
+            if getattr(got, k) != v:
+                raise SystemExit("rank %d: parameter %s = %r after the coefficient broadcast, expected %r" % (rank, k, getattr(got, k), v))
+        # ring: more than the 256 MiB Infinity Cache between two uses of the same buffer
+        bytes_per_buf = 3 * self.n * self.frames * self.frame_len * 4
+        self.ring = max(2, -(-(768 << 20) // bytes_per_buf))
+        self.Is, self.Qs = synth_ring(torch, self.n, self.nco, self.ring, self.frames, self.frame_len, dev, seed=0x5441315F + rank, mode=params.mode)
+        self.q15 = bool(wl.get("q15"))
+        self.bytes_per_sample = 6.0 if self.q15 else BYTES_PER_SAMPLE  # 2 x int16 in + int16 out
+        if self.q15:  # what the codec would deliver for these waveforms
+            self.Is = [(x * 32768.0).round_().clamp_(-32768, 32767).to(torch.int16) for x in self.Is]
+            self.Qs = [(x * 32768.0).round_().clamp_(-32768, 32767).to(torch.int16) for x in self.Qs]
+        self.outs = [torch.empty_like(x) for x in self.Is]
+        self.samples_per_step = self.n * self.frames * self.frame_len
+
+    def step(self, k):
+        r = k % self.ring
+        if self.q15:
+            self.rx.ProcessIQData_q15(self.Qs[r], self.Is[r], out=self.outs[r])  # L queue carries Q, R queue carries I
+        else:
+            self.rx.ProcessIQData(self.Is[r], self.Qs[r], out=self.outs[r])
+
+    def time(self, steps, warmup):
+        """W untimed launches, then exactly K timed ones between barrier + synchronize on both sides.
+        Returns (wall seconds, max over ranks; average launch duration in ms from HIP events on the launch stream)."""
+        torch, dist = self.torch, self.dist
+        for k in range(warmup):
+            self.step(k)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev1 = torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()  # same stream the kernels are enqueued on (torch's current stream)
+        for k in range(steps):
+            self.step(warmup + k)
+        ev1.record()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        kernel_ms = ev0.elapsed_time(ev1) / steps
+        if dist is not None:
+            from t41_sdr_amd.dist import max_over_ranks
+            wall = max_over_ranks(wall, device=self.dev)
+        return wall, kernel_ms
+
+    def roofline(self, kernel_ms):
+        achieved = self.bytes_per_sample * self.samples_per_step / (kernel_ms * 1e-3) / 1e9
+        return {
             "bound": "hbm",
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": load_traffic(args.workload, frames),
-            "kernel": "rx512_kernel" if fft_length == 512 else "rx512_kernel<front> + fastconv_kernel + rx512_kernel<back>",
+            "traffic": load_traffic(self.name, self.frames),
+            "kernel": "rx512_kernel" if self.fft_length == 512 else "rx512_kernel<front> + fastconv_kernel (+ rx512_kernel<back>)",
             "kernel_ms": round(kernel_ms, 5),
-            "us_per_frame": round(kernel_ms * 1e3 / frames, 3),
-            "algorithmic_bytes_per_launch": int(bytes_per_sample * samples_per_step),
+            "us_per_frame": round(kernel_ms * 1e3 / self.frames, 3),
+            "algorithmic_bytes_per_launch": int(self.bytes_per_sample * self.samples_per_step),
             "kernel_source_hash": kernel_source_hash(),
-        },
-    }
-    if rank == 0:
-        if world == 1 and not args.no_cpu_baseline and args.workload == "ssb":
-            line["cpu_baseline"] = cpu_baseline(torch, Is, Qs, nco, params_kw, hi - lo, frame_len)
-        print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        }
+
+    def free(self):
+        self.rx.close()
+        self.Is = self.Qs = self.outs = None
+        self.torch.cuda.empty_cache()
+
+
+def parity_check(torch, w, launches, launches_timed, sample=16):
+    """The launches of the timed run once more, from the power-on state, in the timed launch shape
+    (same buffers, same ring order, same frames per launch), with the audio of `sample` channels
+    copied out after every launch and compared with the CPU oracle run over the same stream:
+    per-frame max|gpu - ref| / max|ref|, the bar 1e-5.  The copies are why this is a
+    replay and not the timed pass itself; the kernel is deterministic, and that the replay
+    reproduces the timed pass is checked bit for bit on every buffer the timed pass left behind."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    L = w.frame_len
+    idx = np.unique(np.linspace(0, w.n - 1, sample).round().astype(np.int64))
+    idx_t = torch.as_tensor(idx, device=w.dev)
+    left = [o.clone() for o in w.outs] if launches == launches_timed else None
+    w.rx.reset()
+    got = []
+    for k in range(launches):
+        w.step(k)
+        got.append(w.outs[k % w.ring].index_select(0, idx_t))
+    torch.cuda.synchronize()
+    replay_identical = None
+    if left is not None:
+        replay_identical = all(torch.equal(a, b) for a, b in zip(left, w.outs))
+    ob = O.OracleBatch(O.default_params(**w.params_kw), np.asarray(w.nco[idx], dtype=np.int32), native=False)
+    threads = max(1, min(host_cpu()[2], len(idx)))
+    hI = [x.index_select(0, idx_t).cpu().numpy() for x in w.Is]
+    hQ = [x.index_select(0, idx_t).cpu().numpy() for x in w.Qs]
+    worst, worst_at, sq_err, sq_ref = 0.0, None, 0.0, 0.0
+    for k in range(launches):
+        r = k % w.ring
+        if w.q15:
+            ref = ob.process_q15(hQ[r], hI[r]).astype(np.float64)
+        else:
+            ref = ob.process(hI[r], hQ[r], nthreads=threads).astype(np.float64)
+        g = got[k].cpu().numpy().astype(np.float64)
+        if w.q15:  # q15 samples: +-1 LSB at truncation boundaries is the documented bar (tests/test_q15_boundary.py)
+            e = np.abs(g - ref).max() / 32768.0
+            if e > worst:
+                worst, worst_at = float(e), [int(k), -1]
+            continue
+        d = np.abs(g - ref).reshape(len(idx), -1, L).max(axis=2)
+        m = np.abs(ref).reshape(len(idx), -1, L).max(axis=2)
+        rel = np.where(m >= 1e-6, d / np.maximum(m, 1e-30), d)
+        if k == 0 and w.params_kw.get("mode") == 8:
+            rel[:, :12] = 0.0  # SAM: the PLL's pull-in is compared once locked (DESIGN.md section 2, tests/test_sam.py)
+        if rel.max() > worst:
+            c, f = np.unravel_index(rel.argmax(), rel.shape)
+            worst, worst_at = float(rel.max()), [int(k), int(f), int(idx[c])]
+        sq_err += float(((g - ref) ** 2).sum())
+        sq_ref += float((ref ** 2).sum())
+    ob.close()
+    # the stated bars: 1e-5 (north_star); AM 5e-5 (the reference's f32 DC blocker, tests/test_gpu_parity.py::test_parity_am); q15 +-1 LSB
+    tol = 1.0 / 32768.0 + 1e-9 if w.q15 else (5e-5 if w.params_kw.get("mode") == 2 else 1e-5)
+    ok = bool(worst <= tol) and replay_identical is not False
+    return {"ok": ok, "max_block_rel_err": worst, "tolerance": tol, "at_launch_frame_channel": worst_at,
+            "rms_rel_err": (sq_err / sq_ref) ** 0.5 if sq_ref > 0 else None,
+            "channels": [int(c) for c in idx], "launches_checked": launches, "launches_timed": launches_timed,
+            "frames_per_launch": w.frames, "replay_bit_identical_to_timed_run": replay_identical,
+            "how": "replay of the timed launches from the power-on state in the timed shape, sampled channels vs oracle/t41_oracle.c"}
 
 
 if __name__ == "__main__":

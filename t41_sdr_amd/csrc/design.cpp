@@ -230,6 +230,7 @@ bool params_valid(const t41rx_params &p, const char **why) {
   if (p.AGCMode < 0 || p.AGCMode > 4) return fail("AGCMode must be 0 (off) .. 4 (fast)");
   if (p.AGC_thresh < -40 || p.AGC_thresh > 120) return fail("AGC_thresh out of -40..120 dB");
   if (p.nfm_demod < 0 || p.nfm_demod > 1) return fail("nfm_demod must be 0 (quadri-correlator) or 1 (atan2 + de-emphasis)");
+  if (p.mode == T41RX_DEMOD_NFM && p.nfm_demod == 1 && p.fft_length != 512) return fail("nfm_demod = 1 is built for fft_length 512");
   return true;
 }
 

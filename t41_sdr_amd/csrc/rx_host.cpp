@@ -129,9 +129,12 @@ int upload_coeffs(t41rx_ctx *ctx) {
   DevCoef dc;
   std::memset(&dc, 0, sizeof(dc));
   std::memcpy(dc.dec1, v.dec1, sizeof(float) * kDec1Taps);
-  std::memcpy(dc.dec2, v.dec2, sizeof(float) * kDec2Taps);
+  // FIR_dec2_coeffs times the level adjust volScaleFactor (Process.cpp:481-492), the multiply right behind that filter
+  for (int i = 0; i < kDec2Taps; ++i) dc.dec2[i] = v.dec2[i] * v.scalars[kScLevel];
   std::memcpy(dc.int1, v.int1, sizeof(float) * kInt1Taps);
-  std::memcpy(dc.int2, v.int2, sizeof(float) * kInt2Taps);
+  // FIR_int2_coeffs times the volume factor DF * VolumeToAmplification(audioVolume) (Process.cpp:929):
+  // the x4 interpolator is the last stage before it, so the kernels apply it through the taps
+  for (int i = 0; i < kInt2Taps; ++i) dc.int2[i] = v.int2[i] * v.scalars[kScOutScale];
   std::memcpy(dc.lp1, v.lp1, sizeof(float) * 5);
   std::memcpy(dc.sc, v.scalars, sizeof(float) * kNumScalars);
   std::memcpy(dc.agc, v.agc, sizeof(float) * kNumAgc);
@@ -535,6 +538,7 @@ int process_device_impl(t41rx_ctx *ctx, const float *dI, const float *dQ, float 
   if (ctx->disp_spec && n_frames > ctx->disp_frames)
     return fail(T41RX_ERR_ARG, "n_frames exceeds the max_frames the display-spectrum buffers were set with");
   if (ctx->disp_spec && q15) return fail(T41RX_ERR_UNSUPPORTED, "the display spectrum is not available on the q15 entry points");
+  if (ctx->disp_spec && (!ctx->d_pre || !ctx->d_disp || !ctx->d_win)) return fail(T41RX_ERR_STATE, "display spectrum enabled without its buffers");
   a.dbg_pre = ctx->disp_spec ? ctx->d_pre : nullptr;
   a.dbg_nco = ctx->dbg_nco;
   a.dbg_dec = ctx->dbg_dec;
@@ -672,6 +676,11 @@ int t41rx_set_state(t41rx_ctx *ctx, const void *host_buf, size_t bytes) {
       return fail(T41RX_ERR_STATE, "checkpoint: AGC state words out of range");
     for (int k = 0; k < 4; ++k)
       if (!std::isfinite(r[ag + k])) return fail(T41RX_ERR_STATE, "checkpoint: AGC levels not finite");
+    // AMDecodeSAM's statics (Demod.cpp:19-23): the kernel wraps phzerror with one conditional step
+    // each way, which is the reference's pair of `while` loops only for a phase already in [0, 2 pi)
+    const float phz = r[kStMisc + kMiscSamPhz], fil = r[kStMisc + kMiscSamFil], om = r[kStMisc + kMiscSamOmega];
+    if (!(phz >= 0.0f && phz < 6.2831855f) || !std::isfinite(fil) || !(std::fabs(fil) < 4.0f) || !(std::fabs(om) <= 1.05f))
+      return fail(T41RX_ERR_STATE, "checkpoint: synchronous-detector PLL words out of range");
   }
   DeviceGuard g(ctx->device);
   HIP_TRY(hipDeviceSynchronize());
@@ -720,7 +729,12 @@ int t41rx_set_display_spectrum(t41rx_ctx *ctx, float *d_spec, float *d_spec_old,
   if (spectrumZoom < 0 || spectrumZoom > 4) return fail(T41RX_ERR_ARG, "spectrumZoom must be 0 (1x) .. 4 (16x)");  // MAX_ZOOM_ENTRIES, ButtonProc.h:6
   if (max_frames <= 0) return fail(T41RX_ERR_ARG, "max_frames must be > 0");
   if ((reinterpret_cast<uintptr_t>(d_spec) | reinterpret_cast<uintptr_t>(d_spec_old)) & 3u) return fail(T41RX_ERR_ARG, "unaligned pointer");
-  if (max_frames > ctx->disp_frames || !ctx->d_pre) {
+  // Anything that fails from here on leaves the side output switched OFF (a previous successful
+  // call's pointers must not survive next to a freed tap buffer: the display kernel would read it).
+  ctx->disp_spec = ctx->disp_old = nullptr;
+  const int had_frames = ctx->disp_frames;
+  ctx->disp_frames = 0;
+  if (max_frames > had_frames || !ctx->d_pre) {
     (void)hipFree(ctx->d_pre);
     ctx->d_pre = nullptr;
     HIP_TRY(hipMalloc((void **)&ctx->d_pre, sizeof(float) * 4096 * (size_t)max_frames * (size_t)ctx->nchan));
@@ -733,6 +747,7 @@ int t41rx_set_display_spectrum(t41rx_ctx *ctx, float *d_spec, float *d_spec_old,
     HIP_TRY(hipMemcpy(ctx->d_win, w, sizeof(w), hipMemcpyHostToDevice));
   }
   HIP_TRY(hipMemset(ctx->d_disp, 0, sizeof(float) * kDispFloats * (size_t)ctx->nchan));  // ZoomFFTPrep(): a fresh start
+  if (max_frames < had_frames) max_frames = had_frames;  // (the tap buffer was kept: it still holds that many)
   ctx->disp_spec = d_spec;
   ctx->disp_old = d_spec_old;
   ctx->disp_frames = max_frames;

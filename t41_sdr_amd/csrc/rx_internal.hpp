@@ -93,9 +93,9 @@ bool params_valid(const t41rx_params &p, const char **why);
 // scalar-loadable coefficient struct, uniform for every wave
 struct DevCoef {
   float dec1[kDec1Taps];
-  float dec2[48];  // 46 used
+  float dec2[48];  // 46 used; FIR_dec2_coeffs x the level adjust sc[kScLevel] (rx_host.cpp: upload_coeffs)
   float int1[kInt1Taps];
-  float int2[kInt2Taps];
+  float int2[kInt2Taps];  // FIR_int2_coeffs x the volume factor sc[kScOutScale] (rx_host.cpp: upload_coeffs)
   float lp1[8];    // 5 used
   float sc[16];    // Scalar enum
   float agc[16];   // AgcConst enum

@@ -1,12 +1,15 @@
 // t41_sdr_amd/csrc/rx_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the T41 RX hot path.
 //
-// One 64-lane wavefront runs one whole ProcessIQData() call (Process.cpp:70-944) for one
-// channel: 2048 complex f32 samples in -> 2048 real f32 samples out, every stage fused, so HBM
-// sees the frame once (16 KiB in + 8 KiB out) plus the ~3 KiB per-channel streaming state.
-// A 256-thread workgroup is four independent waves (one workgroup barrier, for the shared table
-// staging; two more per frame only when the AGC is on); each wave owns a private LDS slice and
-// otherwise synchronises with itself only (LDS is in-order per wave).
-// 16 waves per CU x 256 CUs = 4096 channels in flight = BASELINE config 2's batch.
+// One 64-lane wavefront runs ProcessIQData() (Process.cpp:70-944) for one channel, every stage
+// fused, for ALL the frames of a launch: 2048 complex f32 samples in -> 2048 real f32 samples out
+// per frame, so HBM sees each frame once (16 KiB in + 8 KiB out).  FFT_LENGTH 512, AGC off: one
+// 16-wave workgroup per CU owns all 160 KiB of LDS and the channel's ~3.8 KiB streaming state
+// stays on chip (LDS + registers) between the first and the last frame of the launch (Geo<0>);
+// one workgroup barrier, for the shared twiddle staging; each wave otherwise synchronises with
+// itself only (LDS is in-order per wave).  AGC on / SAM / the long-FFT part kernels: 4-wave
+// workgroups, four per CU, state through HBM per frame, two more barriers per frame around the
+// serial gain law / PLL.  16 waves per CU x 256 CUs = 4096 channels in flight = BASELINE
+// config 2's batch.
 //
 // Stage map (reference file:line -> code below):
 //   gains, DC high-pass           Process.cpp:117-134        front_end()   (parallel affine scan)
@@ -56,7 +59,7 @@ __device__ __forceinline__ void wave_sync() {
   asm volatile("" ::: "memory");
 }
 
-// Timing experiments (tools/build_ablations.sh): T41RX_ABLATE = n cuts stages from the END of the
+// Timing experiments (tools/ablation_table.py): T41RX_ABLATE = n cuts stages from the END of the
 // chain (1 interpolators, 2 FFTs, 3 /2 decimator, 4 /4 decimator, 5 NCO, 6 DC high-pass, 7 1-KiB
 // store instructions, 8 the fused kernel's 16 x 64 B store instructions); 9 keeps all arithmetic but makes every wave use the same 16 channels'
 // buffers (cache-resident I/O).  Outputs are WRONG for n > 0; the product builds with 0.
@@ -378,24 +381,40 @@ __device__ __forceinline__ f2 hp_scan(f2 B, float m15, float m31) {
   B = pk_fma(splat(T.scanA[1]), dpp_f2<kDppRowShr2, 0xf, true>(B), B);
   B = pk_fma(splat(T.scanA[2]), dpp_f2<kDppRowShr4, 0xf, true>(B), B);
   B = pk_fma(splat(T.scanA[3]), dpp_f2<kDppRowShr8, 0xf, true>(B), B);
-  B = pk_fma(splat(m15), dpp_f2<kDppRowBcast15, 0xa, false>(B), B);
-  B = pk_fma(splat(m31), dpp_f2<kDppRowBcast31, 0xc, false>(B), B);
-  return B;
+  // the two row-stitching steps as v_fmac_f32 with the DPP operand built in (VOP2; the packed
+  // form needs the shuffled value in a register first, zeroed for the rows the step leaves alone):
+  // rows outside row_mask are simply not written
+  // (inline asm: hipcc does not fold a DPP move into the multiply-add; the s_nop are the two wait
+  // states a DPP read needs after a VALU write of its source, which the compiler does not insert
+  // inside an asm statement)
+  float bx = B.x, by = B.y;
+  asm("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %1, %1, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 0\n\tv_fmac_f32_dpp %0, %0, %3 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %1, %1, %3 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 0"  // (a DPP read of %1 may follow)
+      : "+v"(bx), "+v"(by)
+      : "v"(m15), "v"(m31));
+  return f2{bx, by};
 }
 
 // Runs the recurrence over `n` consecutive (I, Q) samples per lane (lane-major: lane l owns
 // samples l*n .. l*n+n-1), all 64 lanes in parallel: local pass with zero carry, wave scan of
 // the carries, rank-1 fix-up.  `carry` (wave-uniform pair) is the filter state entering lane 0
 // for the I chain and the Q chain and is replaced by the state leaving lane 63.
+// x arrives PRE-SCALED by b0 (the caller folds it into the RF-gain multiply it does anyway): with
+// b1 = -b0 the step is then y = x' + d, d' = a1 y - x' -- two packed operations per (I, Q) sample
+// instead of three (b0 x and b1 x each round once here; the reference rounds b0 x inside the sum:
+// a difference of one ulp of x, far inside the path's tolerance).
+static_assert(kHpB1 == -kHpB0, "the pre-scaled form of the DC high-pass needs b1 = -b0");
 template <int n>
 __device__ __forceinline__ void dc_highpass(f2 (&x)[n], f2 &carry, int lane, float m15, float m31) {
   constexpr HpTab<n> T{};
-  const float b0 = (float)kHpB0, b1 = (float)kHpB1, a1 = (float)kHpA1;
+  const float a1 = (float)kHpA1;
   f2 d = (lane == 0) ? carry : splat(0.0f);
 #pragma unroll
   for (int k = 0; k < n; ++k) {
-    const f2 y = pk_fma(splat(b0), x[k], d);
-    d = pk_fma(splat(a1), y, splat(b1) * x[k]);
+    const f2 y = x[k] + d;
+    d = pk_fma(splat(a1), y, -x[k]);
     x[k] = y;
   }
   const f2 B = hp_scan<n>(d, m15, m31);
@@ -1381,13 +1400,15 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC)>::kWaves * 64), 4) void 
       }
       // gains (Process.cpp:117-134, 165-166).  g_band and -IQAmp are folded into one factor on I
       // (exact whenever either is +-1, which is the firmware default; one rounding otherwise)
-      float g_rf, g_rf_i, iq_phase_neg = 0.0f, iq_phase_pos = 0.0f;
+      float g_rf, g_rf_i, g_hp, g_hp_i, iq_phase_neg = 0.0f, iq_phase_pos = 0.0f;
       f2 g_iq = splat(1.0f);
       {
         g_rf = a.g_rf;
         if (WQ15) g_rf *= 1.0f / 32768.0f;  // arm_q15_to_float
         // PLAIN: sign of the I path (-1 when the IQ amplitude correction applies, Process.cpp:165-173)
         g_rf_i = (PLAIN && a.iq_corr_on) ? -g_rf : g_rf;
+        g_hp = g_rf * (float)kHpB0;  // what the samples are multiplied by: the DC high-pass takes b0 x (dc_highpass)
+        g_hp_i = (PLAIN && a.iq_corr_on) ? -g_hp : g_hp;
         if (!PLAIN) {
           const float gb = a.g_band;
           const bool iq_on = a.iq_corr_on != 0;
@@ -1441,20 +1462,20 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC)>::kWaves * 64), 4) void 
       auto rebuild_from = [&](float4 rI0, float4 rI1, float4 rQ0, float4 rQ1, uint64_t phase_end) -> f2 {
         cf z[8];
         if (!WQ15) {
-          z[0] = cf{rI0.x * g_rf_i, rQ0.x * g_rf};
-          z[1] = cf{rI0.y * g_rf_i, rQ0.y * g_rf};
-          z[2] = cf{rI0.z * g_rf_i, rQ0.z * g_rf};
-          z[3] = cf{rI0.w * g_rf_i, rQ0.w * g_rf};
-          z[4] = cf{rI1.x * g_rf_i, rQ1.x * g_rf};
-          z[5] = cf{rI1.y * g_rf_i, rQ1.y * g_rf};
-          z[6] = cf{rI1.z * g_rf_i, rQ1.z * g_rf};
-          z[7] = cf{rI1.w * g_rf_i, rQ1.w * g_rf};
+          z[0] = cf{rI0.x * g_hp_i, rQ0.x * g_hp};
+          z[1] = cf{rI0.y * g_hp_i, rQ0.y * g_hp};
+          z[2] = cf{rI0.z * g_hp_i, rQ0.z * g_hp};
+          z[3] = cf{rI0.w * g_hp_i, rQ0.w * g_hp};
+          z[4] = cf{rI1.x * g_hp_i, rQ1.x * g_hp};
+          z[5] = cf{rI1.y * g_hp_i, rQ1.y * g_hp};
+          z[6] = cf{rI1.z * g_hp_i, rQ1.z * g_hp};
+          z[7] = cf{rI1.w * g_hp_i, rQ1.w * g_hp};
         } else {
           const float wi[4] = {rI0.x, rI0.y, rI0.z, rI0.w}, wq[4] = {rQ0.x, rQ0.y, rQ0.z, rQ0.w};
   #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            z[2 * k] = cf{q15_lo(wi[k]) * g_rf_i, q15_lo(wq[k]) * g_rf};
-            z[2 * k + 1] = cf{q15_hi(wi[k]) * g_rf_i, q15_hi(wq[k]) * g_rf};
+            z[2 * k] = cf{q15_lo(wi[k]) * g_hp_i, q15_lo(wq[k]) * g_hp};
+            z[2 * k + 1] = cf{q15_hi(wi[k]) * g_hp_i, q15_hi(wq[k]) * g_hp};
           }
         }
         f2 dcs = splat(0.0f);
@@ -1562,20 +1583,20 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC)>::kWaves * 64), 4) void 
           // -- RF gain (Process.cpp:117-119); the multiply also interleaves I and Q into pairs
           cf z[8];
           if (!WQ15) {
-            z[0] = cf{pI0[h].x * g_rf_i, pQ0[h].x * g_rf};
-            z[1] = cf{pI0[h].y * g_rf_i, pQ0[h].y * g_rf};
-            z[2] = cf{pI0[h].z * g_rf_i, pQ0[h].z * g_rf};
-            z[3] = cf{pI0[h].w * g_rf_i, pQ0[h].w * g_rf};
-            z[4] = cf{pI1[h].x * g_rf_i, pQ1[h].x * g_rf};
-            z[5] = cf{pI1[h].y * g_rf_i, pQ1[h].y * g_rf};
-            z[6] = cf{pI1[h].z * g_rf_i, pQ1[h].z * g_rf};
-            z[7] = cf{pI1[h].w * g_rf_i, pQ1[h].w * g_rf};
+            z[0] = cf{pI0[h].x * g_hp_i, pQ0[h].x * g_hp};
+            z[1] = cf{pI0[h].y * g_hp_i, pQ0[h].y * g_hp};
+            z[2] = cf{pI0[h].z * g_hp_i, pQ0[h].z * g_hp};
+            z[3] = cf{pI0[h].w * g_hp_i, pQ0[h].w * g_hp};
+            z[4] = cf{pI1[h].x * g_hp_i, pQ1[h].x * g_hp};
+            z[5] = cf{pI1[h].y * g_hp_i, pQ1[h].y * g_hp};
+            z[6] = cf{pI1[h].z * g_hp_i, pQ1[h].z * g_hp};
+            z[7] = cf{pI1[h].w * g_hp_i, pQ1[h].w * g_hp};
           } else {  // arm_q15_to_float (x / 32768, exact) is part of g_rf here
             const float wi[4] = {pI0[h].x, pI0[h].y, pI0[h].z, pI0[h].w}, wq[4] = {pQ0[h].x, pQ0[h].y, pQ0[h].z, pQ0[h].w};
   #pragma unroll
             for (int k = 0; k < 4; ++k) {
-              z[2 * k] = cf{q15_lo(wi[k]) * g_rf_i, q15_lo(wq[k]) * g_rf};
-              z[2 * k + 1] = cf{q15_hi(wi[k]) * g_rf_i, q15_hi(wq[k]) * g_rf};
+              z[2 * k] = cf{q15_lo(wi[k]) * g_hp_i, q15_lo(wq[k]) * g_hp};
+              z[2 * k + 1] = cf{q15_hi(wi[k]) * g_hp_i, q15_hi(wq[k]) * g_hp};
             }
           }
           if (s < 2) {  // refill this register set with the sub-block after next
@@ -1796,12 +1817,7 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC)>::kWaves * 64), 4) void 
       if (AGC && lane < 52) agst = *reinterpret_cast<const float4 *>(st + st_agc(512) + 4 * lane);
       wave_sync();
 
-      // ---- level adjust (Process.cpp:481-492)
-      const float level = fresh_coef(cf0)->sc[kScLevel];
-  #pragma unroll
-      for (int rd = 0; rd < 2; ++rd)
-  #pragma unroll
-        for (int e = 0; e < 2; ++e) y2[rd][e] *= splat(level);
+      // ---- level adjust (Process.cpp:481-492): folded into the /2 decimator's taps by the host (DevCoef::dec2)
       if (DEBUG && a.dbg_dec) {
         float *dd = a.dbg_dec + ((size_t)ch * a.nframes + f) * N;
   #pragma unroll
@@ -2280,9 +2296,8 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC)>::kWaves * 64), 4) void 
     // 7-sample history is the neighbouring lane's tail (lane 0: last frame's, from HBM)
     {
       float w[15];
-      const float out_scale = fresh_coef(cf0)->sc[kScOutScale];
       float c4[32];
-      load_taps<32>(c4, (CFloatPtr)cf0->int2);
+      load_taps<32>(c4, (CFloatPtr)cf0->int2);  // (pre-multiplied by the volume factor)
       const float x1[8] = {u1[0].x, u1[0].y, u1[1].x, u1[1].y, u1[2].x, u1[2].y, u1[3].x, u1[3].y};
 #pragma unroll
       for (int i = 0; i < 7; ++i) {
@@ -2328,7 +2343,7 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC)>::kWaves * 64), 4) void 
       // meanwhile: the /4 history (lanes 0..13) and the /2 history (lanes 16..39) share one
       // float4, the part of the overlap block below float 2048 (lanes 0..22) takes another.
       // (Two half-size transpositions instead -- 64-byte store segments -- cost 8..17 % of the
-      // whole kernel: measured, tools/variant_sweep.py nores_half.)
+      // whole kernel: measured, tools/build_variant.sh -DT41RX_X_HALFTR=1.)
       constexpr bool PARK = KEEP && !WQ15 && !T41RX_X_HALFTR;
       constexpr int kOvPark = (2048 - G::kOV + 3) / 4;  // float4s of the overlap block below float 2048
       static_assert(!PARK || (kOvPark > 0 && kOvPark <= 64 && G::kH1 >= 2048), "parking layout");
@@ -2350,9 +2365,8 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC)>::kWaves * 64), 4) void 
           o01 = pk_fma(x, f2{c4[4 * t + 3], c4[4 * t + 2]}, o01);
           o23 = pk_fma(x, f2{c4[4 * t + 1], c4[4 * t]}, o23);
         }
-        // ---- volume (Process.cpp:929)
-        o01 *= splat(out_scale);
-        o23 *= splat(out_scale);
+        // ---- volume (Process.cpp:929): DF * VolumeToAmplification() is folded into the x4 taps by the host
+        // (DevCoef::int2), one rounding per tap instead of one per output
         if (!WQ15 && !HALFTR) {
           *reinterpret_cast<float4 *>(tr + 4 * (8 * lane + (u ^ (lane & 7)))) = make_float4(o01.x, o01.y, o23.x, o23.y);
         } else if (!WQ15) {
@@ -2756,7 +2770,6 @@ __global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_kern
       }
       float c4[32];  // the x4 interpolator's taps, likewise
       load_taps<32>(c4, (CFloatPtr)fresh_coef(cf0)->int2);
-      const float out_scale = fresh_coef(cf0)->sc[kScOutScale];
       STAMP(11);
       __syncthreads();
       STAMP(12);
@@ -2793,8 +2806,6 @@ __global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_kern
               o01 = pk_fma(x, f2{c4[4 * t + 3], c4[4 * t + 2]}, o01);
               o23 = pk_fma(x, f2{c4[4 * t + 1], c4[4 * t]}, o23);
             }
-            o01 *= splat(out_scale);
-            o23 *= splat(out_scale);
             *reinterpret_cast<float4 *>(tr + 4 * (8 * lane + (u ^ (lane & 7)))) = make_float4(o01.x, o01.y, o23.x, o23.y);
           }
           wave_sync();

@@ -39,7 +39,9 @@ struct Guard {
     if (prev >= 0) (void)hipSetDevice(prev);
   }
 };
-bool valid(const t41tx_params &p) { return p.mode >= T41RX_DEMOD_USB && p.mode <= T41RX_DEMOD_NFM; }
+// every mode the receive side accepts: ExciterIQData() runs in all of them and only applies the TX
+// IQ correction in LSB / USB (Exciter.cpp:117-140)
+bool valid(const t41tx_params &p) { return (p.mode >= T41RX_DEMOD_USB && p.mode <= T41RX_DEMOD_NFM) || p.mode == T41RX_DEMOD_SAM; }
 void free_ctx(t41tx_ctx *c) {
   if (!c) return;
   (void)hipFree(c->d_state);

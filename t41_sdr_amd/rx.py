@@ -107,6 +107,9 @@ class RxChain:
     def set_coeffs(self, blob):
         blob = np.ascontiguousarray(blob, dtype=np.uint8)
         check(self._lib.t41rx_set_coeffs(self._ctx, blob.ctypes.data_as(C.c_void_p), blob.size))
+        # the context now runs the parameters the blob was designed for: a later CalcFilters(one
+        # field) must start from THEM, not from what this object was created with
+        self.params = self.get_params()
 
     def reset(self):
         check(self._lib.t41rx_reset(self._ctx))

@@ -93,6 +93,7 @@ def test_bench_launcher_starts_its_own_ranks(built):
     d = lines[0]
     assert d["dry_run"] is True and d["n_gpus"] == 2 and d["world_size_observed"] == 2
     assert d["channels"] == [0, 4096] and d["wall_max"] == 2.0
+    assert sorted(d["local_ranks"]) == [0, 1]  # every rank would select its own device
 
 
 def test_bench_refuses_a_world_size_mismatch(built):

@@ -1,0 +1,151 @@
+#!/usr/bin/env python3
+"""Ablation table of the fused FFT_LENGTH 512 kernel (BASELINE config 2): where the frame's time goes.
+
+Each row is a build of rx_kernels.hip with -DT41RX_ABLATE=n (see that file): stages are cut from the END
+of the chain (1 interpolators, 2 + FFTs, 3 + /2 decimator, 4 + /4 decimator, 5 + oscillator, 6 + DC
+high-pass, 7 = every arithmetic stage gone, the loads / LDS staging / 1-KiB stores kept: "memory
+only"), 9 = all arithmetic but every wave works on the same 16 channels' buffers (cache-resident
+I/O: "arithmetic only").  Outputs of n > 0 are wrong by construction; only the product row is a kernel.
+
+  python tools/ablation_table.py build            (here: hipcc cross-compiles, ~45 s per variant)
+  python tools/ablation_table.py run  [--rounds 3] [--frames 32] [--out gpurun_out/r03_ablation_ssb.md]   (GPU box)
+  python tools/ablation_table.py one NAME         (one timing of one variant; what `run` starts per cell and what
+                                                   tools/ablation_round.sh puts under rocprofv3 --kernel-trace --stats)
+
+`run` interleaves the variants over several rounds (one process per cell: a process binds one
+libt41rx build) and reports the median and the minimum per variant, so drift of the box's clock
+between rows is visible instead of being read as a kernel property.
+"""
+import json
+import os
+import statistics
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+VARIANTS = [
+    ("product", None, "the kernel as shipped"),
+    ("abl1", 1, "without the x2 / x4 interpolators (stores kept)"),
+    ("abl2", 2, "... and without the two 512-point FFTs + mask"),
+    ("abl3", 3, "... and without the /2 decimator"),
+    ("abl4", 4, "... and without the /4 decimator"),
+    ("abl5", 5, "... and without the oscillator / mixer"),
+    ("abl6", 6, "... and without the DC high-pass"),
+    ("abl7", 7, "memory only: loads, LDS staging, 1-KiB stores; no arithmetic"),
+    ("abl9", 9, "arithmetic only: every wave on the same 16 channels' buffers (cache-resident I/O)"),
+]
+L = 2048
+ALG_BYTES_PER_FRAME = 12 * 4096 * L
+
+
+def lib_path(name):
+    return None if name == "product" else os.path.join(ROOT, "t41_sdr_amd", "abl", "libt41rx_%s.so" % name)
+
+
+def build():
+    for name, n, _ in VARIANTS:
+        if n is None:
+            continue
+        print("building", name, flush=True)
+        subprocess.check_call([os.path.join(ROOT, "tools", "build_variant.sh"), name, "-DT41RX_ABLATE=%d" % n])
+
+
+def one(frames, reps):
+    """HIP-event time per frame of the library this process bound (T41RX_LIB), config 2's shape"""
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import torch
+    import t41_sdr_amd as T
+    nch = 4096
+    rng = np.random.default_rng(1000)
+    nco = (rng.integers(-860, 801, nch) * 50).astype(np.int32)
+    rx = T.RxChain(nch, T.default_params(), NCOFreq=nco)
+    ring = max(2, -(-(768 << 20) // (3 * nch * frames * L * 4)))
+    g = torch.Generator(device="cuda").manual_seed(0)
+    Is = [(0.2 * torch.randn(nch, frames * L, generator=g, device="cuda")).clamp_(-0.999, 0.999) for _ in range(ring)]
+    Qs = [(0.2 * torch.randn(nch, frames * L, generator=g, device="cuda")).clamp_(-0.999, 0.999) for _ in range(ring)]
+    out = [torch.empty(nch, frames * L, device="cuda") for _ in range(ring)]
+    for k in range(max(6, reps // 4)):
+        rx.ProcessIQData(Is[k % ring], Qs[k % ring], out=out[k % ring])
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for k in range(reps):
+        rx.ProcessIQData(Is[k % ring], Qs[k % ring], out=out[k % ring])
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3 / frames
+
+
+def run(rounds, frames, reps, out_path):
+    res = {name: [] for name, _, _ in VARIANTS}
+    for r in range(rounds):
+        for name, _, _ in VARIANTS:
+            lp = lib_path(name)
+            if lp is not None and not os.path.exists(lp):
+                continue
+            env = dict(os.environ)
+            env.pop("T41RX_LIB", None)
+            if lp:
+                env["T41RX_LIB"] = lp
+            p = subprocess.run([sys.executable, os.path.abspath(__file__), "one", name, "--frames", str(frames), "--reps", str(reps)],
+                               env=env, capture_output=True, text=True, timeout=600)
+            cells = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+            if p.returncode != 0 or not cells:
+                print("variant %s failed: %s" % (name, p.stderr[-400:]), flush=True)
+                continue
+            res[name].append(cells[0]["us_per_frame"])
+            print("round %d %-8s %.2f us per frame" % (r, name, cells[0]["us_per_frame"]), flush=True)
+    lines = ["# Ablation of `rx512_kernel<SSB, PLAIN>` (config 2: 4096 channels x %d frames x 2048 samples per launch)" % frames, "",
+             "HIP-event time per 4096-channel frame, %d launches per cell, %d interleaved rounds, one process per cell "
+             "(`tools/ablation_table.py run`).  GB/s = 12 B x 4096 x 2048 per frame over that time." % (reps, rounds), "",
+             "| build | what is left | median us | min us | GB/s at the median | of 8 TB/s |", "|---|---|---|---|---|---|"]
+    for name, _, what in VARIANTS:
+        v = res[name]
+        if not v:
+            continue
+        med, mn = statistics.median(v), min(v)
+        gbs = ALG_BYTES_PER_FRAME / med / 1e3
+        lines.append("| %s | %s | %.2f | %.2f | %.0f | %.3f |" % (name, what, med, mn, gbs, gbs / 8000.0))
+    if res["product"]:
+        base = statistics.median(res["product"])
+        prev = base
+        lines += ["", "Cost of each stage = the step between two consecutive cuts (medians):", "",
+                  "| stage | us per frame | share of the product's time |", "|---|---|---|"]
+        for name, label in (("abl1", "x2 + x4 interpolators"), ("abl2", "512-point FFT, mask, inverse FFT"), ("abl3", "/2 decimator"),
+                            ("abl4", "/4 decimator"), ("abl5", "oscillator + mixer"), ("abl6", "DC high-pass"),
+                            ("abl7", "gain / interleave, demodulator, transposition arithmetic")):
+            if not res[name]:
+                continue
+            cur = statistics.median(res[name])
+            lines.append("| %s | %.2f | %.1f %% |" % (label, prev - cur, 100.0 * (prev - cur) / base))
+            prev = cur
+        lines.append("| memory-only skeleton (abl7) | %.2f | %.1f %% |" % (prev, 100.0 * prev / base))
+    text = "\n".join(lines) + "\n"
+    print(text)
+    if out_path:
+        os.makedirs(os.path.dirname(os.path.abspath(out_path)), exist_ok=True)
+        with open(out_path, "w") as f:
+            f.write(text)
+        with open(os.path.splitext(out_path)[0] + ".json", "w") as f:
+            json.dump({"frames_per_launch": frames, "launches_per_cell": reps, "us_per_frame": res}, f, indent=1)
+
+
+def main():
+    args = sys.argv[1:]
+    if not args or args[0] not in ("build", "run", "one"):
+        raise SystemExit(__doc__)
+
+    def opt(flag, default):
+        return type(default)(args[args.index(flag) + 1]) if flag in args else default
+    if args[0] == "build":
+        build()
+    elif args[0] == "one":
+        us = one(opt("--frames", 32), opt("--reps", 60))
+        print(json.dumps({"variant": args[1] if len(args) > 1 else "product", "us_per_frame": round(us, 3)}), flush=True)
+    else:
+        run(opt("--rounds", 3), opt("--frames", 32), opt("--reps", 60), opt("--out", os.path.join(ROOT, "gpurun_out", "r03_ablation_ssb.md")))
+
+
+if __name__ == "__main__":
+    main()

@@ -155,23 +155,40 @@ def launch_ranks(n, argv):
 # ------------------------------------------------------------------------------------------
 # the workload
 # ------------------------------------------------------------------------------------------
-def synth_ring(torch, n_channels, nco_hz, ring, frames, frame_len, device, seed, mode=0):
+def synth_ring(torch, n_channels, nco_hz, ring, frames, frame_len, device, seed, mode=0, flo=200, fhi=3000):
     """RING launch buffers of `frames` consecutive frames of SURVEY 8d's synthetic signal, built on
-    the GPU.  Returns lists of [n_channels, frames * frame_len] float32 tensors (I, Q)."""
+    the GPU.  Returns lists of [n_channels, frames * frame_len] float32 tensors (I, Q).
+    Three tones + noise per channel; the first tone is what the channel is tuned to: a tone inside the
+    filter's pass band (SSB / AM), a carrier 100 Hz off tune (SAM), or -- NFM -- a sinusoidally
+    frequency-modulated carrier on the tuned frequency with the other two tones kept at least 20 kHz
+    away from it (a discriminator fed two carriers of similar strength divides by their beat nulls:
+    its output is then ill-conditioned in ANY arithmetic, which says nothing about the kernel)."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     nco = torch.as_tensor(np.asarray(nco_hz, dtype=np.float64), device=device)
     amps = 0.05 + 0.25 * torch.rand(n_channels, 3, generator=g, device=device, dtype=torch.float64)
     freqs = -90000.0 + 180000.0 * torch.rand(n_channels, 3, generator=g, device=device, dtype=torch.float64)
     phases = 2 * np.pi * torch.rand(n_channels, 3, generator=g, device=device, dtype=torch.float64)
-    audio = 400.0 + 2100.0 * torch.rand(n_channels, generator=g, device=device, dtype=torch.float64)
+    lo, hi = (max(flo, 0), fhi) if fhi > 0 else (-fhi, -flo)      # the audio band the filter passes
+    lo, hi = lo + 0.1 * (hi - lo), hi - 0.1 * (hi - lo)            # (inside its edges: 420..580 Hz for the 400..600 Hz filter)
+    lo, hi = max(lo, min(400.0, hi)), min(hi, max(2500.0, lo))     # SURVEY 8d's 400..2500 Hz where the filter is wider
+    audio = lo + (hi - lo) * torch.rand(n_channels, generator=g, device=device, dtype=torch.float64)
     freqs[:, 0] = 48000.0 - nco - audio  # lands at +audio Hz in the USB pass band (I sign flip, +Fs/4, -NCO)
+    fm_dev = fm_rate = fm_phase = None
     if mode == 8:  # SAM: the first tone is the carrier, 100 Hz off the tuned frequency
         freqs[:, 0] = 48000.0 - nco - 100.0
         amps[:, 0] = 0.3
-    if mode == 3:  # NFM: no I sign flip; put a carrier on the tuned frequency
+    if mode == 3:  # NFM: no I sign flip; an FM carrier on the tuned frequency
         freqs[:, 0] = -48000.0 + nco
         amps[:, 0] = 0.3
+        fm_rate = 300.0 + 2200.0 * torch.rand(n_channels, 1, generator=g, device=device, dtype=torch.float64)
+        fm_dev = 0.5 + 2.0 * torch.rand(n_channels, 1, generator=g, device=device, dtype=torch.float64)  # modulation index
+        fm_phase = 2 * np.pi * torch.rand(n_channels, 1, generator=g, device=device, dtype=torch.float64)
+        for k in (1, 2):  # interferers: outside +-20 kHz of the carrier (folded back into +-96 kHz)
+            off = 20000.0 + 56000.0 * torch.rand(n_channels, generator=g, device=device, dtype=torch.float64)
+            sign = torch.where(torch.rand(n_channels, generator=g, device=device, dtype=torch.float64) < 0.5, -1.0, 1.0)
+            f = freqs[:, 0] + sign * off
+            freqs[:, k] = torch.remainder(f + 96000.0, 192000.0) - 96000.0
     Is, Qs = [], []
     # a few large chunks rather than many small ones: fewer dispatches (rocprofv3 --pmc has segfaulted inside torch's
     # element-wise launches when a profiled run made tens of thousands of them), ~256 MiB per float64 temporary
@@ -187,6 +204,8 @@ def synth_ring(torch, n_channels, nco_hz, ring, frames, frame_len, device, seed,
             im = torch.zeros_like(re)
             for k in range(3):
                 ph = (2 * np.pi / FS) * freqs[:, k:k + 1] * n[None, :] + phases[:, k:k + 1]
+                if k == 0 and fm_dev is not None:
+                    ph = ph + fm_dev * torch.sin((2 * np.pi / FS) * fm_rate * n[None, :] + fm_phase)
                 re += amps[:, k:k + 1] * torch.cos(ph)
                 im += amps[:, k:k + 1] * torch.sin(ph)
             noise = torch.randn(2, n_channels, chunk, generator=g, device=device, dtype=torch.float32)
@@ -437,7 +456,8 @@ class Workload:
         # ring: more than the 256 MiB Infinity Cache between two uses of the same buffer
         bytes_per_buf = 3 * self.n * self.frames * self.frame_len * 4
         self.ring = max(2, -(-(768 << 20) // bytes_per_buf))
-        self.Is, self.Qs = synth_ring(torch, self.n, self.nco, self.ring, self.frames, self.frame_len, dev, seed=0x5441315F + rank, mode=params.mode)
+        self.Is, self.Qs = synth_ring(torch, self.n, self.nco, self.ring, self.frames, self.frame_len, dev, seed=0x5441315F + rank,
+                                      mode=params.mode, flo=params.FLoCut, fhi=params.FHiCut)
         self.q15 = bool(wl.get("q15"))
         self.bytes_per_sample = 6.0 if self.q15 else BYTES_PER_SAMPLE  # 2 x int16 in + int16 out
         if self.q15:  # what the codec would deliver for these waveforms

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define T41RX_ABI_VERSION 3
+#define T41RX_ABI_VERSION 4
 
 /* status codes */
 #define T41RX_OK 0
@@ -80,6 +80,16 @@ typedef struct t41rx_params {
                                       commented out: fmdemod_atan_cf (Demod.cpp:368-392, ApproxAtan2 :148-197 with its
                                       2 pi for pi / 2 as written) + limiter + deemphasis_nfm_ff applied block-wise
                                       (Demod.cpp:324-344, Process.cpp:734-735).  fft_length 512 only. */
+  /* The optional stages between the demodulator and the interpolators, Process.cpp:841-866 (all off in the firmware's
+   * defaults).  fft_length 512, f32 entry points; the functions are written for blocks of 256 audio samples. */
+  int32_t nrOptionSelect;          /* gwv.cpp:23: 0 off; 1 Kim1_NR() (Noise.cpp:108-313) then x30; 2 SpectralNoiseReduction()
+                                      (Noise.cpp:379-655); 3 Xanr() as LMS noise reduction (Noise.cpp:322-370) then x1.5 --
+                                      as written the call site scales Xanr()'s INPUT, so 3 only changes the gain (and advances
+                                      the adaptive filter the notch shares) */
+  int32_t ANR_notchOn;             /* Process.cpp:45, :862-866: 1 = Xanr() as automatic notch behind the noise reduction */
+  float   NR_PSI;                  /* gwv.cpp:61 (0.0): Kim1_NR()'s noise-floor switch */
+  float   NR_alpha;                /* gwv.cpp:62 (0.95): time smoothing of the gains (Kim, spectral) */
+  float   NR_beta;                 /* gwv.cpp:63 (0.85): Kim1_NR()'s smoothing over neighbouring bins */
 } t41rx_params;
 
 typedef struct t41rx_ctx t41rx_ctx; /* opaque: coefficient arrays + per-channel state + device buffers */
@@ -98,8 +108,8 @@ void t41rx_default_params(t41rx_params *p);
  * The arrays CalcFilters() (Filter.cpp:235-249), InitFilterMask() (Filter.cpp:260-284),
  * SetDecIntFilters() (Filter.cpp:396-438) and InitializeDataArrays() (T41_SDR.ino:560-566) leave
  * behind, serialised as one blob:
- *   header (24 x int32: magic, abi, fft_length, mode, sizeof(t41rx_params), 3 reserved, then the
- *   t41rx_params the blob was designed for, padded to 16 words) |
+ *   header (32 x int32: magic, abi, fft_length, mode, sizeof(t41rx_params), 3 reserved, then the
+ *   t41rx_params the blob was designed for, padded to 24 words) |
  *   FIR_dec1_coeffs[28] | FIR_dec2_coeffs[46] | FIR_int1_coeffs[48] | FIR_int2_coeffs[32] |
  *   biquad_lowpass1_coeffs[5] | scalars[16] (gains, level adjust, volume, the SAM PLL constants) | AGC constants[16] (what AGCPrep() +
  *   AGCLoadValues() leave behind, DSP_Fn.cpp:368-468; zeros for AGCMode 0) |

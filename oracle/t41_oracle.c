@@ -58,6 +58,11 @@ void t41o_default_params(t41o_params *p) {
   p->am_lpf_f0 = 3000;            /* boot band 40M LSB -200/-3000, T41_SDR.ino:560-563 */
   p->AGC_thresh = 20;             /* bands[] "AGC" column, T41_SDR.ino:145-168 */
   p->nfm_demod = 0;               /* the live code path, Process.cpp:716 */
+  p->nrOptionSelect = 0;          /* gwv.cpp:23 */
+  p->ANR_notchOn = 0;             /* Process.cpp:45 */
+  p->NR_PSI = 0.0;                /* gwv.cpp:61-63 */
+  p->NR_alpha = 0.95;
+  p->NR_beta = 0.85;
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -496,6 +501,7 @@ struct t41o_channel {
   float FFT_ring_buffer_x[512], FFT_ring_buffer_y[512];
   int zoom_sample_ptr;
   float FFT_spec[512], FFT_spec_old[512];
+  t41o_nr *nr;                                        /* Noise.cpp state (t41_nr_oracle.c) */
 };
 
 static float *fzalloc(size_t n) { return (float *)calloc(n, sizeof(float)); }
@@ -536,6 +542,7 @@ t41o_channel *t41o_channel_create(int fft_length) {
   ch->tap_volts = fzalloc((size_t)D);
   ch->agc_abs_ring = fzalloc(AGC_RB_SIZE);
   ch->agc_ring = fzalloc(2 * AGC_RB_SIZE);
+  ch->nr = t41o_nr_create();
   t41o_channel_reset(ch);
   return ch;
 }
@@ -565,8 +572,11 @@ void t41o_channel_destroy(t41o_channel *ch) {
   free(ch->tap_volts);
   free(ch->agc_abs_ring);
   free(ch->agc_ring);
+  t41o_nr_destroy(ch->nr);
   free(ch);
 }
+
+t41o_nr *t41o_channel_nr(t41o_channel *ch) { return ch ? ch->nr : NULL; }
 
 void t41o_channel_reset(t41o_channel *ch) {
   const int L = ch->L, D = ch->D;
@@ -604,6 +614,7 @@ void t41o_channel_reset(t41o_channel *ch) {
   memset(ch->audioSpectBuffer, 0, sizeof(ch->audioSpectBuffer));
   ch->audioMaxSquared = ch->audioMaxSquaredAve = 0.0f;
   ch->AudioMaxIndex = 0;
+  t41o_nr_reset(ch->nr);
 }
 
 int t41o_channel_tap(const t41o_channel *ch, int which, float *dst, int maxlen) {
@@ -1384,6 +1395,12 @@ int t41o_process_frame(t41o_channel *ch, const t41o_params *p, const t41o_coeffs
   }
   memcpy(ch->tap_ifft, iFFT_buffer, sizeof(float) * (size_t)(2 * N));
   memcpy(ch->tap_demod, fL, sizeof(float) * (size_t)D);
+
+  /* noise reduction and automatic notch, Process.cpp:841-866 (written for blocks of 256 samples) */
+  if (p->nrOptionSelect != 0 || p->ANR_notchOn == 1) {
+    if (N != 512 || !t41o_nr_supported(p)) return -4;
+    t41o_nr_block(ch->nr, p, fL, fR);
+  }
 
   /* interpolation, Process.cpp:917-920 (iFFT_buffer is scratch for the x2 stage) */
   t41o_fir_interpolate_f32(c->int1, T41O_N_INT1_TAPS, 2, ch->int1_state, fL, iFFT_buffer, D);

@@ -63,6 +63,12 @@ typedef struct {
   int32_t nfm_demod;        /* 0 = nfmdemod() + limiter, what the firmware runs (Process.cpp:716-727); 1 = the variant
                                the source keeps commented out: fmdemod_atan_cf (Demod.cpp:368-392, ApproxAtan2
                                Demod.cpp:148-197) + limiter + deemphasis_nfm_ff (Demod.cpp:328-344, Process.cpp:734-735) */
+  /* optional post-demodulation stages, Process.cpp:841-866 (oracle/t41_nr_oracle.c); fft_length 512 only */
+  int32_t nrOptionSelect;   /* gwv.cpp:23: 0 off, 1 Kim1_NR() (x30), 2 SpectralNoiseReduction(), 3 Xanr() LMS NR (x1.5) */
+  int32_t ANR_notchOn;      /* Process.cpp:45: 1 = Xanr() as automatic notch behind the noise reduction */
+  float   NR_PSI;           /* gwv.cpp:61 (0.0) */
+  float   NR_alpha;         /* gwv.cpp:62 (0.95) */
+  float   NR_beta;          /* gwv.cpp:63 (0.85) */
 } t41o_params;
 
 /* what AGCPrep() + AGCLoadValues() (DSP_Fn.cpp:368-468) leave in the AGC globals, as f32 */
@@ -122,6 +128,17 @@ float t41o_arm_cos_f32(float x);
 const float *t41o_sin_table(void);
 void t41o_sam_constants(float out[4]);
 
+/* ---- noise reduction / automatic notch, Noise.cpp (oracle/t41_nr_oracle.c) ---- */
+typedef struct t41o_nr t41o_nr;
+t41o_nr *t41o_nr_create(void);
+void t41o_nr_destroy(t41o_nr *s);
+void t41o_nr_reset(t41o_nr *s); /* InitializeDataArrays() + SpectralNoiseReductionInit() + static initialisers */
+/* Process.cpp:841-866 on one block of 256 audio samples @24 kS/s (float_buffer_L in and out, _R scratch) */
+void t41o_nr_block(t41o_nr *s, const t41o_params *p, float *float_buffer_L, float *float_buffer_R);
+int t41o_nr_peek(const t41o_nr *s, int which, float *dst, int maxlen);
+/* 0 when SpectralNoiseReduction() would index outside its arrays for these cut-offs (Noise.cpp:556-574 with NN = 9) */
+int t41o_nr_supported(const t41o_params *p);
+
 /* ---- channel state + the block function ---- */
 t41o_channel *t41o_channel_create(int fft_length);
 void t41o_channel_destroy(t41o_channel *ch);
@@ -168,6 +185,7 @@ enum {
   T41O_TAP_FFT_SPEC_OLD = 11  /* 512: FFT_spec_old (the display's low-pass memory) */
 };
 int t41o_channel_tap(const t41o_channel *ch, int which, float *dst, int maxlen);
+t41o_nr *t41o_channel_nr(t41o_channel *ch); /* the channel's noise-reduction state (tests) */
 /* the display FFT side output (FFT.cpp:67-251): spectrumZoom 0..4 = on (as with updateDisplayFlag == 1
  * in every frame), -1 = off (the default).  Like ZoomFFTPrep(): zoom filters re-initialised, zoom_sample_ptr = 0. */
 int t41o_channel_set_display(t41o_channel *ch, int spectrumZoom);

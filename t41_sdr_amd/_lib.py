@@ -35,6 +35,11 @@ class Params(C.Structure):
         ("am_lpf_f0", C.c_int32),
         ("AGC_thresh", C.c_int32),
         ("nfm_demod", C.c_int32),
+        ("nrOptionSelect", C.c_int32),
+        ("ANR_notchOn", C.c_int32),
+        ("NR_PSI", C.c_float),
+        ("NR_alpha", C.c_float),
+        ("NR_beta", C.c_float),
     ]
 
 

@@ -208,6 +208,32 @@ void design_zoom_fir(int spectrumZoom, float (&coeffs)[4]) {
   kaiser_lowpass(coeffs, 4, Fstop_Zoom, 60, (float)kSampleRate);
 }
 
+// the bins the filter passes, as Kim1_NR() / SpectralNoiseReduction() derive them from bands[].FLoCut / FHiCut
+// (Noise.cpp:134-168, 421-433, 514-531): 93.75 Hz per bin of the 256-point transforms at 24 kS/s
+void nr_vad_range(int FLoCut, int FHiCut, int *lo, int *hi) {
+  float lf_freq, uf_freq;
+  if (FLoCut <= 0 && FHiCut >= 0) {
+    lf_freq = 0.0;
+    uf_freq = std::fmax(-(float)FLoCut, (float)FHiCut);
+  } else if (FLoCut > 0) {
+    lf_freq = (float)FLoCut;
+    uf_freq = (float)FHiCut;
+  } else {
+    uf_freq = -(float)FLoCut;
+    lf_freq = -(float)FHiCut;
+  }
+  lf_freq /= (((float)kSampleRate / kDF) / 256);
+  uf_freq /= (((float)kSampleRate / kDF) / 256);
+  int VAD_low = (uint8_t)(int)lf_freq, VAD_high = (uint8_t)(int)uf_freq;
+  if (VAD_low == VAD_high) VAD_high++;
+  if (VAD_low < 1) VAD_low = 1;
+  else if (VAD_low > 126) VAD_low = 126;
+  if (VAD_high < 1) VAD_high = 1;
+  else if (VAD_high > 128) VAD_high = 128;
+  *lo = VAD_low;
+  *hi = VAD_high;
+}
+
 bool params_valid(const t41rx_params &p, const char **why) {
   auto fail = [&](const char *m) {
     if (why) *why = m;
@@ -231,6 +257,19 @@ bool params_valid(const t41rx_params &p, const char **why) {
   if (p.AGC_thresh < -40 || p.AGC_thresh > 120) return fail("AGC_thresh out of -40..120 dB");
   if (p.nfm_demod < 0 || p.nfm_demod > 1) return fail("nfm_demod must be 0 (quadri-correlator) or 1 (atan2 + de-emphasis)");
   if (p.mode == T41RX_DEMOD_NFM && p.nfm_demod == 1 && p.fft_length != 512) return fail("nfm_demod = 1 is built for fft_length 512");
+  if (p.nrOptionSelect < 0 || p.nrOptionSelect > 3) return fail("nrOptionSelect must be 0 (off), 1 (Kim), 2 (spectral) or 3 (LMS)");
+  if (p.ANR_notchOn < 0 || p.ANR_notchOn > 1) return fail("ANR_notchOn must be 0 or 1");
+  if ((p.nrOptionSelect != 0 || p.ANR_notchOn != 0) && p.fft_length != 512)
+    return fail("noise reduction / notch are written for blocks of 256 audio samples: fft_length 512 only");
+  if (!(p.NR_alpha >= 0.0f && p.NR_alpha <= 1.0f) || !(p.NR_beta >= 0.0f && p.NR_beta <= 1.0f) || !(p.NR_PSI >= 0.0f && p.NR_PSI < 1e30f))
+    return fail("NR_alpha / NR_beta must be in [0, 1], NR_PSI >= 0");
+  if (p.nrOptionSelect == 2) {
+    // SpectralNoiseReduction()'s musical-noise smoothing reaches 2 NN - 1 = 17 bins below VAD_high and 11 above VAD_low
+    // (Noise.cpp:556-574 with NN up to 9): for narrower pass bands the reference indexes outside NR_Nest / NR_G
+    int lo, hi;
+    nr_vad_range(p.FLoCut, p.FHiCut, &lo, &hi);
+    if (hi < 17 || lo + 11 > 127) return fail("nrOptionSelect = 2: the reference indexes outside its arrays for this pass band");
+  }
   return true;
 }
 

@@ -1,0 +1,505 @@
+// t41_sdr_amd/csrc/nr_kernels.hip -- gfx950 kernels of the receive path's optional stages between the
+// demodulator and the interpolators (Process.cpp:841-866): noise reduction (Kim1_NR() Noise.cpp:108-313,
+// SpectralNoiseReduction() Noise.cpp:379-655, Xanr() as LMS noise reduction Noise.cpp:322-370) and the
+// automatic notch (Xanr() again).  All off in the firmware's defaults; FFT_LENGTH 512.
+//
+// They run on the call's demodulated audio @24 kS/s, which the fused kernel leaves in a scratch
+// ([channel][frame * 256], rx_kernels.hip: RxArgs::aud_out), in place, frame by frame; the long-FFT
+// pipeline's back kernel then interpolates (launch_back512).
+//
+//  * anr_kernel: Xanr() is a 64-tap adaptive FIR whose every output feeds back into its taps, sample by
+//    sample, and whose sums the reference accumulates in tap order.  ONE LANE PER CHANNEL: a wave runs 64
+//    channels' filters, every lane the reference's loop as written (same operations, same order, no
+//    contraction -- bit-identical to the scalar code), taps in 64 registers, the delay line's live window
+//    in an LDS tile laid out [time][channel] (row pitch 65 floats: conflict-free both for the transposing
+//    stage-in / stage-out and for the per-lane window reads).  The tile is filled and drained with
+//    coalesced row accesses of the [channel][time] scratch.
+//  * nrspec_kernel<KIND>: the two spectral-weighting functions, one wave per channel.  Both transform
+//    half-overlapped 256-sample frames, two per block, with real input; here the block's two frames ride
+//    as real and imaginary part through ONE 512-point transform of the path's register-resident FFT
+//    (zero-interleaved, so that bins 0..255 hold the 256-point transform), are separated by conjugate
+//    symmetry, weighted, and go back through ONE inverse transform the same way.  The reference weights bin
+//    i together with bin 255 - i (not 256 - i) and keeps the real part of the inverse transform: the real
+//    part sees the conjugate-symmetric half of the weighted spectrum, i.e. bin k weighted by
+//    (G[k] + G[k-1]) / 2 -- which is what is applied here.  Per-bin statistics: two bins per lane.
+#include <hip/hip_runtime.h>
+
+#include "nr_kernels.hpp"
+#include "rx_kernels.hpp"
+#include "wave_fft.hpp"
+
+namespace t41 {
+
+// ------------------------------------------------------------------------------------------
+// Xanr(), one lane per channel
+// ------------------------------------------------------------------------------------------
+constexpr int kAnrRow = 65;                    // LDS row pitch in floats (64 channels + 1)
+constexpr int kAnrTile = kAnrHist + 256;       // rows of the input tile: 79 of history + the frame
+constexpr size_t kAnrLdsBytes = (size_t)(kAnrTile + 256) * kAnrRow * sizeof(float);  // input tile + output tile
+
+// One pass of Noise.cpp:331-369 over the 256 samples in T[kAnrHist ..] for this lane's channel.
+// out (may be null): O tile.
+template <bool NOTCH>
+__device__ __forceinline__ void anr_pass(const float *T, float *O, float (&w)[kAnrTaps], float &lidx, float &ngamma, int lane) {
+#pragma clang fp contract(off)
+  const float ANR_den_mult = 6.25e-10, ANR_gamma = 0.1, ANR_lidx_min = 120.0, ANR_lidx_max = 200.0;
+  const float ANR_lincr = 1.0, ANR_ldecr = 3.0, ANR_two_mu = 0.0001;
+  for (int i = 0; i < 256; ++i) {
+    const float *row = T + i * kAnrRow + lane;
+    const float d_in = row[kAnrHist * kAnrRow];  // ANR_d[ANR_in_idx]
+    float dj[kAnrTaps];
+    float y = 0, sigma = 0;
+#pragma unroll
+    for (int j = 0; j < kAnrTaps; ++j) {  // idx = in_idx + j + ANR_delay: the sample written j + 16 steps ago
+      dj[j] = row[(kAnrTaps - 1 - j) * kAnrRow];
+      y += w[j] * dj[j];
+      sigma += dj[j] * dj[j];
+    }
+    const float inv_sigp = (float)(1.0 / ((double)sigma + 1e-10));
+    const float error = d_in - y;
+    if (O) O[i * kAnrRow + lane] = NOTCH ? error : y;
+    float nel = (float)((double)error * (1.0 - (double)(ANR_two_mu * sigma * inv_sigp)));
+    if (nel < 0.0f) nel = -nel;
+    float nev = (float)((double)d_in - (1.0 - (double)(ANR_two_mu * ngamma)) * (double)y - (double)(ANR_two_mu * error * sigma * inv_sigp));
+    if (nev < 0.0f) nev = -nev;
+    if (nev < nel) {  // as written (Noise.cpp:351-356): the else-if belongs to the inner if
+      lidx += ANR_lincr;
+      if (lidx > ANR_lidx_max) {
+        lidx = ANR_lidx_max;
+      } else {
+        lidx -= ANR_ldecr;
+        if (lidx < ANR_lidx_min) lidx = ANR_lidx_min;
+      }
+    }
+    ngamma = ANR_gamma * (lidx * lidx) * (lidx * lidx) * ANR_den_mult;
+    const float c0 = (float)(1.0 - (double)(ANR_two_mu * ngamma));
+    const float c1 = ANR_two_mu * error * inv_sigp;
+#pragma unroll
+    for (int j = 0; j < kAnrTaps; ++j) w[j] = c0 * w[j] + c1 * dj[j];
+  }
+}
+
+__global__ __launch_bounds__(64, 1) void anr_kernel(const NrArgs a) {
+#pragma clang fp contract(off)
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float *T = sm, *O = sm + kAnrTile * kAnrRow;
+  const int lane = threadIdx.x;
+  const int ch0 = blockIdx.x * 64;
+  const int nlive = (a.nchan - ch0 < 64) ? a.nchan - ch0 : 64;
+  const int ch = ch0 + (lane < nlive ? lane : nlive - 1);  // dead lanes shadow the last live channel (their stores are skipped)
+  const size_t nch = (size_t)a.nchan;
+  float w[kAnrTaps];
+#pragma unroll
+  for (int j = 0; j < kAnrTaps; ++j) w[j] = a.anr[(size_t)(kAnrStW + j) * nch + ch];
+  for (int r = 0; r < kAnrHist; ++r) T[r * kAnrRow + lane] = a.anr[(size_t)(kAnrStHist + r) * nch + ch];
+  float lidx = a.anr[(size_t)kAnrStLidx * nch + ch], ngamma = a.anr[(size_t)kAnrStNgamma * nch + ch];
+  for (int f = 0; f < a.nframes; ++f) {
+    // stage the frame in: row c of the scratch = channel ch0 + c, 256 consecutive samples, 4 x 256 B per row
+    __syncthreads();
+    for (int c = 0; c < nlive; ++c) {
+      const float *src = a.aud + ((size_t)(ch0 + c) * a.nframes + f) * 256;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) T[(kAnrHist + lane + 64 * q) * kAnrRow + c] = src[lane + 64 * q];
+    }
+    for (int c = nlive; c < 64; ++c) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) T[(kAnrHist + lane + 64 * q) * kAnrRow + c] = 0.0f;
+    }
+    __syncthreads();
+    if (a.nr_option == 3) {  // Process.cpp:852-857: Xanr() as noise reduction; its result stays in float_buffer_R, float_buffer_L is scaled by 1.5
+      anr_pass<false>(T, nullptr, w, lidx, ngamma, lane);
+      if (a.notch) {
+        // the notch pass sees the scaled block behind the unscaled one: its delay line = the last 79 unscaled samples
+        for (int r = 0; r < kAnrHist; ++r) T[r * kAnrRow + lane] = T[(256 + r) * kAnrRow + lane];
+        for (int i = 0; i < 256; ++i) T[(kAnrHist + i) * kAnrRow + lane] = T[(kAnrHist + i) * kAnrRow + lane] * 1.5f;
+      } else {
+        for (int i = 0; i < 256; ++i) O[i * kAnrRow + lane] = T[(kAnrHist + i) * kAnrRow + lane] * 1.5f;
+      }
+    }
+    if (a.notch) anr_pass<true>(T, O, w, lidx, ngamma, lane);  // Process.cpp:862-866
+    // the delay line's live part for the next block
+    for (int r = 0; r < kAnrHist; ++r) T[r * kAnrRow + lane] = T[(256 + r) * kAnrRow + lane];
+    __syncthreads();
+    for (int c = 0; c < nlive; ++c) {
+      float *dst = a.aud + ((size_t)(ch0 + c) * a.nframes + f) * 256;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dst[lane + 64 * q] = O[(lane + 64 * q) * kAnrRow + c];
+    }
+  }
+  if (lane < nlive) {
+#pragma unroll
+    for (int j = 0; j < kAnrTaps; ++j) a.anr[(size_t)(kAnrStW + j) * nch + ch] = w[j];
+    for (int r = 0; r < kAnrHist; ++r) a.anr[(size_t)(kAnrStHist + r) * nch + ch] = T[r * kAnrRow + lane];
+    a.anr[(size_t)kAnrStLidx * nch + ch] = lidx;
+    a.anr[(size_t)kAnrStNgamma * nch + ch] = ngamma;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Kim1_NR() / SpectralNoiseReduction(), one wave per channel
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+template <int KIND>
+__global__ __launch_bounds__(64) void nrspec_kernel(const NrArgs a) {
+#pragma clang fp contract(off)
+  __shared__ __attribute__((aligned(16))) float xbuf[8 * kFftRow * 2];  // FFT exchange
+  __shared__ float S[384];          // NR_last_sample_buffer_L | the block's 256 samples
+  __shared__ cf Zs[257];            // the 256-point spectrum of frame 0 + j frame 1 (partner access), [256] = [0]
+  __shared__ cf W0[129], W1[129];   // weighted, conjugate-symmetrised spectra of the two frames, bins 0..128
+  __shared__ float Y0[256], Y1[256];
+  __shared__ float Gb[130];         // gains with one pad either side: Gb[1 + i]
+  __shared__ float Xs[3][128], Es[15][128];
+  __shared__ float Gts1[128], Gts0[128], Gst[128], Lout[128], Nest[128], Pslp[128], Xt[128], Hk[128];
+  const int lane = threadIdx.x;
+  const int ch = blockIdx.x;
+  if (ch >= a.nchan) return;
+  float *st = a.spec + (size_t)ch * kNrSpecFloats;
+  const float *win = a.tab_nr + (KIND == 1 ? kNrTabHann : kNrTabSqrtHann);
+  const cf *tab = reinterpret_cast<const cf *>(a.tab);
+  cf tw1[7], tw2[7];
+#pragma unroll
+  for (int q = 0; q < 7; ++q) {
+    tw1[q] = tab[kTabTw1 + 64 * q + lane];
+    tw2[q] = tab[kTabTw2 + 64 * q + lane];
+  }
+  // ---- the channel's record -> LDS
+  for (int i = lane; i < 3 * 128; i += 64) (&Xs[0][0])[i] = st[kNrX + i];
+  for (int i = lane; i < 15 * 128; i += 64) (&Es[0][0])[i] = st[kNrE + i];
+  for (int i = lane; i < 128; i += 64) {
+    Gts1[i] = st[kNrGts1 + i];
+    Gts0[i] = st[kNrGts0 + i];
+    Gst[i] = st[kNrG + i];
+    S[i] = st[kNrLastIn + i];
+    Lout[i] = st[kNrLastOut + i];
+    Nest[i] = st[kNrNest + i];
+    Pslp[i] = st[kNrPslp + i];
+    Xt[i] = st[kNrXt + i];
+    Hk[i] = st[kNrHk + i];
+  }
+  int xp = (int)st[kNrScal + 0], ep = (int)st[kNrScal + 1], first_time_2 = (int)st[kNrScal + 2], init_counter = (int)st[kNrScal + 3];
+  const int lo = a.vad_lo, hi = a.vad_hi;
+  const float NR_alpha = a.alpha, NR_beta = a.beta, NR_PSI = a.psi;
+  __syncthreads();
+
+  // SpectralNoiseReduction()'s per-call constants and statics (Noise.cpp:394-419)
+  const float tinc = 0.00533333, tax = 0.0239, tap = 0.05062, psthr = 0.99, pnsaf = 0.01, asnr = 20, psini = 0.5, pspri = 0.5;
+  const float ax = expf(-tinc / tax), ap = expf(-tinc / tap);
+  const float xih1 = powf(10, (float)asnr / 10.0);
+  const float xih1r = 1.0 / (1.0 + xih1) - 1.0;
+  const float pfac = (1.0 / pspri - 1.0) * (1.0 + xih1);
+  const float snr_prio_min = powf(10, -(float)20 / 20.0);
+  const float power_threshold = 0.4;
+  const int NR_width = 4;
+
+  if (KIND == 2 && first_time_2 == 1) {  // Noise.cpp:439-450
+    for (int i = lane; i < 128; i += 64) {
+      S[i] = 0.0;
+      Gst[i] = 1.0;
+      Hk[i] = 1.0;
+      Nest[i] = 0.0;
+      Pslp[i] = 0.5;
+    }
+    first_time_2 = 2;
+    __syncthreads();
+  }
+
+  float *gio = a.aud + (size_t)ch * a.nframes * 256;
+  for (int f = 0; f < a.nframes; ++f) {
+    // ---- the block, behind the previous block's second half
+#pragma unroll
+    for (int q = 0; q < 4; ++q) S[128 + lane + 64 * q] = gio[(size_t)f * 256 + lane + 64 * q];
+    __syncthreads();
+    // ---- both frames through one transform: z[n] = w[n] (S[n] + j S[128 + n]), zero-interleaved
+    cf v[8];
+    {
+      const int m = lane >> 1;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int n = m + 32 * r;
+        const float wn = win[n];
+        const cf z = cf{S[n] * wn, S[128 + n] * wn};
+        v[r] = (lane & 1) ? cf{0.0f, 0.0f} : z;
+      }
+    }
+    __syncthreads();
+    if (lane < 64) {  // the second half becomes NR_last_sample_buffer_L
+      S[lane] = S[256 + lane];
+      S[64 + lane] = S[320 + lane];
+    }
+    fft512<false>(v, tw1, tw2, xbuf, lane);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Zs[lane + 64 * r] = v[r];
+    if (lane == 0) Zs[256] = v[0];
+    __syncthreads();
+    // ---- separate: F0[k] = (Z[k] + conj Z[256-k]) / 2, F1[k] = (Z[k] - conj Z[256-k]) / 2j; bins lane, lane + 64
+    cf F[2][2];     // [frame][r]
+    float X[2][2];  // squared magnitudes
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int k = lane + 64 * r;
+      const cf za = Zs[k], zp = Zs[256 - k];
+      F[0][r] = cf{0.5f * (za.x + zp.x), 0.5f * (za.y - zp.y)};
+      F[1][r] = cf{0.5f * (za.y + zp.y), -0.5f * (za.x - zp.x)};
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) X[k2][r] = F[k2][r].x * F[k2][r].x + F[k2][r].y * F[k2][r].y;
+    }
+    const cf z128 = Zs[128];  // F0[128] = Re, F1[128] = Im
+    bool proc[2] = {true, true};
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) {
+      float G[2] = {0.0f, 0.0f};  // this frame's NR_G for my two bins
+      if (KIND == 1) {
+        // ---- Kim1_NR(), Noise.cpp:197-257
+        const float NR_KIM_K = 1.0;
+        const float NR_onemalpha = (1.0 - NR_alpha);
+        const float NR_onemtwobeta = (1.0 - (2.0 * NR_beta));
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const int i = lane + 64 * r;
+          Xs[xp][i] = X[k2][r];
+          if (i >= lo && i < hi) {
+            float NR_sum = 0.0;
+            NR_sum = NR_sum + Xs[0][i];
+            NR_sum = NR_sum + Xs[1][i];
+            NR_sum = NR_sum + Xs[2][i];
+            const float E = NR_sum / (float)3;
+            Es[ep][i] = E;
+            float M = Es[0][i];
+            for (int j = 1; j < 15; ++j)
+              if (Es[j][i] < M) M = Es[j][i];
+            const float NR_T = X[k2][r] / M;
+            const float lambda = (NR_T > NR_PSI) ? M : E;
+            float g = (float)(1.0 - (double)(lambda * NR_KIM_K / E));
+            if (g < 0.0f) g = 0.0f;
+            const float gts = NR_alpha * Gts1[i] + NR_onemalpha * g;
+            Gts0[i] = gts;
+            Gts1[i] = gts;
+          }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const int i = lane + 64 * r;
+          if (i == 0) G[r] = (NR_onemtwobeta + NR_beta) * Gts0[0] + NR_beta * Gts0[1];
+          else if (i == 127) G[r] = NR_beta * Gts0[126] + (NR_onemtwobeta + NR_beta) * Gts0[127];
+          else G[r] = NR_beta * Gts0[i - 1] + NR_onemtwobeta * Gts0[i] + NR_beta * Gts0[i + 1];
+        }
+        xp = (xp + 1 >= 3) ? 0 : xp + 1;
+        ep = (ep + 1 >= 15) ? 0 : ep + 1;
+      } else {
+        // ---- SpectralNoiseReduction(), Noise.cpp:476-601
+        if (first_time_2 == 2) {
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            const int i = lane + 64 * r;
+            const float ne = (float)((double)Nest[i] + 0.05 * (double)X[k2][r]);
+            Nest[i] = ne;
+            Xt[i] = psini * ne;
+          }
+          init_counter++;
+          if (init_counter > 19) {
+            init_counter = 0;
+            first_time_2 = 3;
+          }
+        }
+        proc[k2] = (first_time_2 == 3);
+        if (first_time_2 == 3) {
+          float post[2], prio[2];
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            const int i = lane + 64 * r;
+            const float x = X[k2][r];
+            float xt = Xt[i];
+            float ph1y = (float)(1.0 / (1.0 + (double)(pfac * expf(xih1r * x / xt))));
+            const float ps = (float)((double)(ap * Pslp[i]) + (1.0 - (double)ap) * (double)ph1y);
+            Pslp[i] = ps;
+            if (ps > psthr) ph1y = (float)(1.0 - (double)pnsaf);
+            else ph1y = (float)fmin((double)ph1y, 1.0);
+            const float xtr = (float)((1.0 - (double)ph1y) * (double)x + (double)(ph1y * xt));
+            xt = (float)((double)(ax * xt) + (1.0 - (double)ax) * (double)xtr);
+            Xt[i] = xt;
+            post[r] = (float)fmax(fmin((double)(x / xt), 1000.0), (double)snr_prio_min);
+            prio[r] = (float)fmax((double)(NR_alpha * Hk[i]) + (1.0 - (double)NR_alpha) * fmax((double)post[r] - 1.0, 0.0), 0.0);
+          }
+          __syncthreads();
+          // pre_power: the same sum in every pass of the loop below
+          float pre_part = 0.0f;
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            const int i = lane + 64 * r;
+            if (i >= lo && i < hi) pre_part += X[k2][r];
+          }
+          const float pre_power = wave_sum(pre_part);
+          for (int i = lo; i < hi; ++i) {  // Noise.cpp:529-588: the musical-noise treatment runs inside this loop
+            if (lane == (i & 63)) {
+              const int r = i >> 6;
+              const float pr = r ? prio[1] : prio[0], po = r ? post[1] : post[0];
+              const float vv = (float)((double)(pr * po) / (1.0 + (double)pr));
+              const float g = (float)(1.0 / (double)po * (double)sqrtf((float)(0.7212 * (double)vv + (double)(vv * vv))));
+              Gst[i] = g;
+              Hk[i] = po * g * g;
+            }
+            __syncthreads();
+            float post_part = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+              const int j = lane + 64 * r;
+              if (j >= lo && j < hi) post_part += Gst[j] * Gst[j] * X[k2][r];
+            }
+            const float post_power = wave_sum(post_part);
+            float power_ratio = post_power / pre_power;
+            int NN;
+            if (power_ratio > power_threshold) {
+              power_ratio = 1.0;
+              NN = 1;
+            } else {
+              NN = 1 + 2 * (int)(0.5 + (double)NR_width * (1.0 - (double)(power_ratio / power_threshold)));
+            }
+            if (NN > 1) {
+              // centred average over NN bins; the reference's upper-edge pass (a backward average) overwrites the
+              // centred value of the last NN - NN/2 inner bins before the copy back (Noise.cpp:556-584)
+              const int h = NN / 2;
+              float nv[2] = {0.0f, 0.0f};
+              bool mine[2] = {false, false};
+#pragma unroll
+              for (int r = 0; r < 2; ++r) {
+                const int j = lane + 64 * r;
+                if (j >= lo + h && j < hi - h) {
+                  mine[r] = true;
+                  float s = 0.0;
+                  if (j >= hi - NN) {
+                    for (int m = j; m > j - NN; --m) s += Gst[m];
+                  } else {
+                    for (int m = j - h; m <= j + h; ++m) s += Gst[m];
+                  }
+                  nv[r] = s / (float)NN;
+                }
+              }
+              __syncthreads();
+#pragma unroll
+              for (int r = 0; r < 2; ++r)
+                if (mine[r]) Gst[lane + 64 * r] = nv[r];
+            }
+            __syncthreads();
+          }
+#pragma unroll
+          for (int r = 0; r < 2; ++r) G[r] = Gst[lane + 64 * r] * 1.0f;  // x NR_long_tone_gain (1.0, Noise.cpp:706)
+        }
+      }
+      // ---- this frame's weighted spectrum, conjugate-symmetrised: bin k by (G[k] + G[k-1]) / 2 (bin 0: G[0]; 128: G[127])
+      __syncthreads();
+      Gb[1 + lane] = G[0];
+      Gb[65 + lane] = G[1];
+      __syncthreads();
+      cf *Wk = k2 ? W1 : W0;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int k = lane + 64 * r;
+        const float g = (k == 0) ? Gb[1] : 0.5f * (Gb[1 + k] + Gb[k]);
+        Wk[k] = (k == 0) ? cf{F[k2][r].x * g, 0.0f} : cf{F[k2][r].x * g, F[k2][r].y * g};
+      }
+      if (lane == 0) Wk[128] = cf{(k2 ? z128.y : z128.x) * Gb[128], 0.0f};
+      __syncthreads();
+    }
+    // ---- one inverse transform for both frames: V[k] = W0[k] + j W1[k], V[256 - k] = conj W0[k] + j conj W1[k]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = lane + 64 * r;
+      const int kk = (k <= 128) ? k : 256 - k;
+      const cf a0 = W0[kk], a1 = W1[kk];
+      const float sg = (k <= 128) ? 1.0f : -1.0f;
+      // a0 (+-conj) + j a1 (+-conj): re = a0.x - sg a1.y, im = sg a0.y + a1.x
+      v[r] = cf{a0.x - sg * a1.y, sg * a0.y + a1.x};
+      v[r + 4] = v[r];
+    }
+    fft512<true>(v, tw1, tw2, xbuf, lane);
+    if (!(lane & 1)) {
+      const int m = lane >> 1;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int n = m + 32 * r;
+        const float sw = (KIND == 2) ? win[n] : 1.0f;  // the spectral function windows again after the inverse transform
+        Y0[n] = v[r].x * (1.0f / 512.0f) * sw;
+        Y1[n] = v[r].y * (1.0f / 512.0f) * sw;
+      }
+    }
+    __syncthreads();
+    // ---- overlap-add (Noise.cpp:289-296 / 640-647), Kim: x 30 (Process.cpp:846)
+    {
+      float o[4];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int i = lane + 64 * q;
+        const float l0 = Lout[i];
+        float first, l1;
+        if (proc[0]) {
+          first = Y0[i] + l0;
+          l1 = Y0[128 + i];
+        } else {
+          first = gio[(size_t)f * 256 + i];
+          l1 = l0;
+        }
+        float second, l2;
+        if (proc[1]) {
+          second = Y1[i] + l1;
+          l2 = Y1[128 + i];
+        } else {
+          second = gio[(size_t)f * 256 + 128 + i];
+          l2 = l1;
+        }
+        Lout[i] = l2;
+        o[q] = (KIND == 1) ? first * 30.0f : first;
+        o[2 + q] = (KIND == 1) ? second * 30.0f : second;
+      }
+      gio[(size_t)f * 256 + lane] = o[0];
+      gio[(size_t)f * 256 + 64 + lane] = o[1];
+      gio[(size_t)f * 256 + 128 + lane] = o[2];
+      gio[(size_t)f * 256 + 192 + lane] = o[3];
+    }
+    __syncthreads();
+  }
+  // ---- the record back
+  for (int i = lane; i < 3 * 128; i += 64) st[kNrX + i] = (&Xs[0][0])[i];
+  for (int i = lane; i < 15 * 128; i += 64) st[kNrE + i] = (&Es[0][0])[i];
+  for (int i = lane; i < 128; i += 64) {
+    st[kNrGts1 + i] = Gts1[i];
+    st[kNrGts0 + i] = Gts0[i];
+    st[kNrG + i] = Gst[i];
+    st[kNrLastIn + i] = S[i];
+    st[kNrLastOut + i] = Lout[i];
+    st[kNrNest + i] = Nest[i];
+    st[kNrPslp + i] = Pslp[i];
+    st[kNrXt + i] = Xt[i];
+    st[kNrHk + i] = Hk[i];
+  }
+  if (lane == 0) {
+    st[kNrScal + 0] = (float)xp;
+    st[kNrScal + 1] = (float)ep;
+    st[kNrScal + 2] = (float)first_time_2;
+    st[kNrScal + 3] = (float)init_counter;
+  }
+}
+
+hipError_t launch_nr(const NrArgs &a, hipStream_t s) {
+  if (a.nr_option == 1)
+    hipLaunchKernelGGL((nrspec_kernel<1>), dim3(a.nchan), dim3(64), 0, s, a);
+  else if (a.nr_option == 2)
+    hipLaunchKernelGGL((nrspec_kernel<2>), dim3(a.nchan), dim3(64), 0, s, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  if (a.nr_option == 3 || a.notch) {
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&anr_kernel),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAnrLdsBytes);
+    if (attr != hipSuccess) return attr;
+    hipLaunchKernelGGL(anr_kernel, dim3((a.nchan + 63) / 64), dim3(64), kAnrLdsBytes, s, a);
+    e = hipGetLastError();
+  }
+  return e;
+}
+
+}  // namespace t41

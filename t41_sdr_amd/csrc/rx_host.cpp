@@ -296,6 +296,11 @@ void t41rx_default_params(t41rx_params *p) {
   p->CWFreqShift = 750;
   p->am_lpf_f0 = 3000;               // boot band 40 m: max(FHiCut, -FLoCut) = 3000
   p->AGC_thresh = 20;                // bands[] "AGC" column, T41_SDR.ino:145-168
+  p->nrOptionSelect = 0;             // gwv.cpp:23
+  p->ANR_notchOn = 0;                // Process.cpp:45
+  p->NR_PSI = 0.0;                   // gwv.cpp:61-63
+  p->NR_alpha = 0.95;
+  p->NR_beta = 0.85;
 }
 
 size_t t41rx_coeff_blob_bytes(int fft_length) {

@@ -17,10 +17,11 @@ constexpr int kInt2Taps = 32;        // T41_SDR.ino:608-616 (L=4, phase length 8
 // ---- coefficient blob (host, canonical reference layout; what RCCL broadcasts) ----
 constexpr uint32_t kBlobMagic = 0x54343152u;  // "T41R"
 // header: magic, abi, fft_length, mode, sizeof(t41rx_params), 3 reserved | the t41rx_params the blob
-// was designed for, padded to 16 words.  A context that installs the blob (t41rx_set_coeffs: the
+// was designed for, padded to 24 words.  A context that installs the blob (t41rx_set_coeffs: the
 // broadcast path) takes its parameters from here, so every rank ends up with the designer's.
-constexpr int kBlobHeaderInts = 8 + 16;
-static_assert(sizeof(t41rx_params) <= 16 * sizeof(int32_t), "params section of the blob header");
+constexpr int kBlobParamInts = 24;
+constexpr int kBlobHeaderInts = 8 + kBlobParamInts;
+static_assert(sizeof(t41rx_params) <= kBlobParamInts * sizeof(int32_t), "params section of the blob header");
 constexpr int kNumScalars = 16;
 enum Scalar {
   kScRfGain = 0,      // (float)pow(10, rfGainAllBands/20), Process.cpp:117
@@ -88,6 +89,7 @@ constexpr int kDispFloats = kDispOld + 512;
 // host designer (design.cpp)
 int design_blob(const t41rx_params &p, void *blob, size_t blob_bytes);
 bool params_valid(const t41rx_params &p, const char **why);
+void nr_vad_range(int FLoCut, int FHiCut, int *lo, int *hi);  // Kim / spectral NR: bins [lo, hi) the filter passes
 
 // ---- device-side constant block (one per context) ----
 // scalar-loadable coefficient struct, uniform for every wave

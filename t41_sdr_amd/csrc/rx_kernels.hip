@@ -43,22 +43,13 @@
 
 #include "rx_internal.hpp"
 #include "rx_kernels.hpp"
+#include "wave_fft.hpp"
 
 namespace t41 {
 
 // ------------------------------------------------------------------------------------------
 // small device helpers
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void wave_sync() {
-  // Orders this wave's LDS traffic (other lanes' writes -> my reads).  The LDS unit executes
-  // one wave's instructions in issue order, so no s_waitcnt or workgroup barrier is needed:
-  // only the COMPILER must not move memory operations across this point.
-  asm volatile("" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_sched_barrier(0);  // also pin ALU work: keeps register live ranges per phase
-  asm volatile("" ::: "memory");
-}
-
 // Timing experiments (tools/ablation_table.py): T41RX_ABLATE = n cuts stages from the END of the
 // chain (1 interpolators, 2 FFTs, 3 /2 decimator, 4 /4 decimator, 5 NCO, 6 DC high-pass, 7 1-KiB
 // store instructions, 8 the fused kernel's 16 x 64 B store instructions); 9 keeps all arithmetic but makes every wave use the same 16 channels'
@@ -116,123 +107,6 @@ __device__ __forceinline__ void wave_sync() {
 #define STAMP_PARAMS
 #define STAMP_ARGS
 #endif
-
-typedef float f2 __attribute__((ext_vector_type(2)));
-typedef f2 cf;  // .x = re / I, .y = im / Q, one even-aligned VGPR pair
-
-__device__ __forceinline__ f2 splat(float s) { return f2{s, s}; }
-__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
-
-// complex a*b: (ax bx - ay by, ax by + ay bx) in two packed instructions
-__device__ __forceinline__ cf cmul(cf a, cf b) {
-  cf t, r;
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(t) : "v"(a), "v"(b));
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
-  return r;
-}
-// complex a*conj(b): (ax bx + ay by, ay bx - ax by)
-__device__ __forceinline__ cf cmulc(cf a, cf b) {
-  cf t, r;
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(b));
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
-  return r;
-}
-// same as cmul with b wave-uniform in an SGPR pair
-__device__ __forceinline__ cf cmul_s(cf a, cf b_uniform) {
-  cf t, r;
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(t) : "v"(a), "s"(b_uniform));
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(a), "s"(b_uniform), "v"(t));
-  return r;
-}
-// a + (-j) b = (ax + by, ay - bx)   and   a + j b = (ax - by, ay + bx)
-__device__ __forceinline__ cf add_mj(cf a, cf b) {
-  cf r;
-  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ cf add_pj(cf a, cf b) {
-  cf r;
-  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-
-// 8-point DFT in registers, natural order in and out.  INV selects e^{+j...}.  26 packed ops.
-template <bool INV>
-__device__ __forceinline__ void dft8(cf (&v)[8]) {
-  constexpr float kR = 0.70710678118654752440f;
-  const cf a0 = v[0] + v[4], a1 = v[0] - v[4];
-  const cf a2 = v[2] + v[6], a3 = v[2] - v[6];
-  const cf a4 = v[1] + v[5], a5 = v[1] - v[5];
-  const cf a6 = v[3] + v[7], a7 = v[3] - v[7];
-  const cf b0 = a0 + a2, b1 = a0 - a2;
-  const cf b2 = a4 + a6, b3 = a4 - a6;
-  // forward: W4 = -j, W8 = (1-j)/sqrt2, W8^3 = (-1-j)/sqrt2; inverse: conjugates
-  const cf c0 = INV ? add_pj(a1, a3) : add_mj(a1, a3);
-  const cf c1 = INV ? add_mj(a1, a3) : add_pj(a1, a3);
-  const cf d0 = INV ? add_pj(a5, a7) : add_mj(a5, a7);
-  const cf d1 = INV ? add_mj(a5, a7) : add_pj(a5, a7);
-  // W8 d0 = kR (d0 + (-j) d0) fwd / kR (d0 + j d0) inv;  W8^3 d1 = -kR (d1 + j d1) fwd / -kR (d1 + (-j) d1) inv
-  const cf t0 = INV ? add_pj(d0, d0) : add_mj(d0, d0);
-  const cf t1 = INV ? add_mj(d1, d1) : add_pj(d1, d1);
-  v[0] = b0 + b2;
-  v[4] = b0 - b2;
-  v[2] = INV ? add_pj(b1, b3) : add_mj(b1, b3);
-  v[6] = INV ? add_mj(b1, b3) : add_pj(b1, b3);
-  v[1] = pk_fma(t0, splat(kR), c0);
-  v[5] = pk_fma(t0, splat(-kR), c0);
-  v[3] = pk_fma(t1, splat(-kR), c1);
-  v[7] = pk_fma(t1, splat(kR), c1);
-}
-
-// LDS exchange buffer row stride for the FFT transposes (in complex elements): 64 + 8 keeps
-// both the row-major writes and the 8-strided reads bank-conflict-free for ds_*_b64.
-constexpr int kFftRow = 72;
-// Second exchange: element (q, l1) of a row sits at q + 8 l1 + (l1 & 6).  The extra term spreads
-// the ds_write_b64 of 16 consecutive lanes (q in {2g, 2g+1}, l1 = 0..7) over all 16 8-byte bank
-// pairs (plain 8 l1 is 4-way conflicted: 8 l1 mod 16 has two values); rows stay disjoint (max 69).
-__device__ __forceinline__ constexpr int fft_x2(int l1) { return 8 * l1 + (l1 & 6); }
-
-// 512-point complex FFT held as 8 points per lane: lane l register r <-> element l + 64 r,
-// on input AND output (natural order both ways, no bit-reversal pass).
-//   stage 1: DFT8 over r (stride 64), twiddle W512^(l q)
-//   stage 2: DFT8 over bits 3..5 of l, twiddle W64^((l&7) q2)
-//   stage 3: DFT8 over bits 0..2 of l
-// tw1/tw2: this lane's 7+7 forward twiddles (INV conjugates them on the fly).
-template <bool INV>
-__device__ __forceinline__ void fft512(cf (&v)[8], const cf (&tw1)[7], const cf (&tw2)[7],
-                                       float *__restrict__ xbuf, int lane) {
-  cf *xb = reinterpret_cast<cf *>(xbuf);
-  dft8<INV>(v);
-#pragma unroll
-  for (int q = 1; q < 8; ++q) v[q] = INV ? cmulc(v[q], tw1[q - 1]) : cmul(v[q], tw1[q - 1]);
-  // exchange 1: (reg q, lane l1 + 8 k2) -> (reg k2, lane l1 + 8 q)
-  wave_sync();
-#pragma unroll
-  for (int q = 0; q < 8; ++q) xb[q * kFftRow + lane] = v[q];
-  wave_sync();
-  {
-    const int l1 = lane & 7, q = lane >> 3;
-#pragma unroll
-    for (int k2 = 0; k2 < 8; ++k2) v[k2] = xb[q * kFftRow + l1 + 8 * k2];
-  }
-  dft8<INV>(v);
-#pragma unroll
-  for (int q = 1; q < 8; ++q) v[q] = INV ? cmulc(v[q], tw2[q - 1]) : cmul(v[q], tw2[q - 1]);
-  // exchange 2: (reg q2, lane l1 + 8 q) -> (reg l1, lane q + 8 q2)
-  wave_sync();
-  {
-    const int l1 = lane & 7, q = lane >> 3;
-#pragma unroll
-    for (int q2 = 0; q2 < 8; ++q2) xb[q2 * kFftRow + q + fft_x2(l1)] = v[q2];
-  }
-  wave_sync();
-  {
-    const int q = lane & 7, q2 = lane >> 3;
-#pragma unroll
-    for (int l1 = 0; l1 < 8; ++l1) v[l1] = xb[q2 * kFftRow + q + fft_x2(l1)];
-  }
-  dft8<INV>(v);
-}
 
 // The same with the twiddles read from the workgroup's LDS tables right where they are used
 // (tw1l: this lane's column of tw1[7][64]; tw2l: its column of the compacted tw2[7][8]) instead of
@@ -348,27 +222,6 @@ struct HpTab {
     for (int k = 0; k < n; ++k) pw[k] = (float)cpow(kHpA1, k);
   }
 };
-
-// GFX9 DPP controls: data moves between lanes inside the VALU, no LDS round trip
-constexpr int kDppRowShr1 = 0x111, kDppRowShr2 = 0x112, kDppRowShr4 = 0x114, kDppRowShr8 = 0x118;
-constexpr int kDppWaveShr1 = 0x138, kDppRowBcast15 = 0x142, kDppRowBcast31 = 0x143;
-template <int CTRL, int ROW_MASK, bool BOUND>
-__device__ __forceinline__ float dpp_f(float old, float src) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, ROW_MASK, 0xf, BOUND));
-}
-template <int CTRL, int ROW_MASK, bool BOUND>
-__device__ __forceinline__ f2 dpp_f2(f2 src) {
-  return f2{dpp_f<CTRL, ROW_MASK, BOUND>(0.0f, src.x), dpp_f<CTRL, ROW_MASK, BOUND>(0.0f, src.y)};
-}
-template <int CTRL, int ROW_MASK, bool BOUND>
-__device__ __forceinline__ double dpp_d(double x) {
-  const long long u = __double_as_longlong(x);
-  const int lo = __builtin_amdgcn_update_dpp(0, (int)u, CTRL, ROW_MASK, 0xf, BOUND);
-  const int hi = __builtin_amdgcn_update_dpp(0, (int)(u >> 32), CTRL, ROW_MASK, 0xf, BOUND);
-  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-// value of lane-1 (lane 0 gets 0)
-__device__ __forceinline__ float lane_up1(float v) { return dpp_f<kDppWaveShr1, 0xf, true>(0.0f, v); }
 
 // Inclusive wave scan of the affine carry map d_out = A d_in + B with the same A = a1^n on
 // every lane: 4 row_shr steps inside each 16-lane row, then row_bcast:15 / row_bcast:31 to
@@ -2235,9 +2088,23 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC)>::kWaves * 64), 4) void 
     if (T41RX_CUT(1)) {
 #pragma unroll
       for (int u = 0; u < 8; ++u)
+        // (1-KiB store instructions like the product's, so that the staged cuts time the arithmetic they
+        // remove and not a worse store pattern; 8: the 16 x 64 B form)
         *reinterpret_cast<float4 *>(gO + (T41RX_ABLATE == 8 ? 32 * (16 * (u & 3) + (lane >> 2)) + 16 * (u >> 2) + 4 * (lane & 3)
-                                          : T41RX_CUT(7)    ? 4 * lane + 256 * u
-                                                            : 32 * lane + 4 * u)) = make_float4(aud[0], aud[1], aud[2], aud[3]);
+                                                            : 4 * lane + 256 * u)) = make_float4(aud[0], aud[1], aud[2], aud[3]);
+      continue;
+    }
+    if (DEBUG && PART == 0 && a.aud_out) {
+      // noise reduction / notch on (Process.cpp:841-866): those stages sit between the demodulator and the
+      // interpolators and run in kernels of their own (nr_kernels.hip) on the whole call's audio; this kernel
+      // hands over the 256 samples of the frame in time order and leaves the interpolator memories alone
+      float *ao = a.aud_out + ((size_t)ch * a.nframes + f) * D;
+      if (CONTIG) {
+        *reinterpret_cast<float4 *>(ao + 4 * lane) = make_float4(aud[0], aud[1], aud[2], aud[3]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ao[lane + 64 * j] = aud[j];
+      }
       continue;
     }
     FRESH_LANE();
@@ -3109,8 +2976,17 @@ static hipError_t launch_long(const RxArgs &a, int mode, hipStream_t s) {
   return hipGetLastError();
 }
 
+hipError_t launch_back512(const RxArgs &a, hipStream_t s) {
+  // the long-FFT pipeline's segment-parallel back kernel with one segment per frame: it takes its interpolator
+  // memories from the channel's record and leaves the call's last ones there
+  if (a.seg != 1 || !a.aud24 || a.q15) return hipErrorInvalidValue;
+  const int grid_par = (int)(((size_t)a.nchan * (size_t)((a.nframes + a.seg_run - 1) / a.seg_run) + 3) / 4);
+  hipLaunchKernelGGL((rx512_kernel<kModeSsb, false, 2, false, false, false, true>), dim3(grid_par), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_rx(const RxArgs &a, int fft_length, int mode, hipStream_t s) {
-  const bool debug = a.dbg_nco || a.dbg_dec || a.dbg_demod || a.spect || a.dbg_pre;  // side outputs ride on the tap kernels
+  const bool debug = a.dbg_nco || a.dbg_dec || a.dbg_demod || a.spect || a.dbg_pre || a.aud_out;  // side outputs (and the NR hand-over) ride on the tap kernels
   if (fft_length == 1024 || fft_length == 2048 || fft_length == 4096) {
     if (a.seg * 512 != fft_length) return hipErrorInvalidValue;
     return launch_long(a, mode, s);

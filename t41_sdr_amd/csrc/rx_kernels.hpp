@@ -62,6 +62,10 @@ struct RxArgs {
   int nfm_atan;            // NFM: 1 = atan2 discriminator + block-wise de-emphasis (t41rx_params::nfm_demod)
   int seg_run;             // long FFT, segment-parallel kernels: consecutive segments one wave runs
   int nco_rd;              // long FFT: which of the two NcoState copies holds the call's start state (the other is written)
+  // noise reduction / notch pipeline (FFT_LENGTH 512, tap kernels): when set, the fused kernel stops behind the
+  // demodulator and leaves the frame's 256 audio samples @24 kS/s here, [nchan][nframes * 256] in time order;
+  // nr_kernels.hip then runs Process.cpp:841-866 on them in place and launch_back512() interpolates (aud24 = this)
+  float *aud_out;
 };
 
 // constant table of the N = 512 R point fast convolution (float2 units):
@@ -70,6 +74,8 @@ struct RxArgs {
 constexpr int tab_long_entries(int R) { return (R - 1) * 512 + R * 512; }
 
 hipError_t launch_rx(const RxArgs &a, int fft_length, int mode, hipStream_t s);
+// FFT_LENGTH 512, behind launch_rx() with aud_out set: interpolators, volume and stores from a.aud24 (f32 samples out)
+hipError_t launch_back512(const RxArgs &a, hipStream_t s);
 
 // display FFT (CalcZoom1Magn / ZoomFFTExe, FFT.cpp:67-251) on the dbg_pre tap of the frames just processed
 struct DispArgs {

@@ -39,7 +39,7 @@ def design_coeffs(params):
     return blob
 
 
-BLOB_HEADER_WORDS = 24   # magic, abi, fft_length, mode, sizeof(params), 3 reserved | t41rx_params padded to 16 words
+BLOB_HEADER_WORDS = 32   # magic, abi, fft_length, mode, sizeof(params), 3 reserved | t41rx_params padded to 24 words
 STATE_HEADER_BYTES = 32  # checkpoint header: magic, abi, fft_length, n_channels, floats per channel, 3 reserved
 
 

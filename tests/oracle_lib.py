@@ -39,6 +39,11 @@ class Params(C.Structure):
         ("am_lpf_f0", C.c_int32),
         ("AGC_thresh", C.c_int32),
         ("nfm_demod", C.c_int32),
+        ("nrOptionSelect", C.c_int32),
+        ("ANR_notchOn", C.c_int32),
+        ("NR_PSI", C.c_float),
+        ("NR_alpha", C.c_float),
+        ("NR_beta", C.c_float),
     ]
 
 
@@ -60,9 +65,8 @@ _lib = None
 def build(native=False):
     target = "libt41oracle_native.so" if native else "libt41oracle.so"
     path = os.path.join(ORACLE_DIR, target)
-    src = os.path.join(ORACLE_DIR, "t41_oracle.c")
-    hdr = os.path.join(ORACLE_DIR, "t41_oracle.h")
-    if (not os.path.exists(path)) or os.path.getmtime(path) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    deps = [os.path.join(ORACLE_DIR, f) for f in ("t41_oracle.c", "t41_tx_oracle.c", "t41_nr_oracle.c", "t41_oracle.h")]
+    if (not os.path.exists(path)) or os.path.getmtime(path) < max(os.path.getmtime(f) for f in deps):
         subprocess.check_call(["make", "-C", ORACLE_DIR, target], stdout=subprocess.DEVNULL)
     return path
 
@@ -105,6 +109,16 @@ def lib(native=False):
     L.t41o_channel_tap.restype = C.c_int
     L.t41o_channel_set_display.argtypes = [C.c_void_p, C.c_int]
     L.t41o_channel_set_display.restype = C.c_int
+    L.t41o_nr_create.restype = C.c_void_p
+    L.t41o_nr_destroy.argtypes = [C.c_void_p]
+    L.t41o_nr_reset.argtypes = [C.c_void_p]
+    L.t41o_nr_block.argtypes = [C.c_void_p, C.POINTER(Params), fp, fp]
+    L.t41o_nr_peek.argtypes = [C.c_void_p, C.c_int, fp, C.c_int]
+    L.t41o_nr_peek.restype = C.c_int
+    L.t41o_nr_supported.argtypes = [C.POINTER(Params)]
+    L.t41o_nr_supported.restype = C.c_int
+    L.t41o_channel_nr.argtypes = [C.c_void_p]
+    L.t41o_channel_nr.restype = C.c_void_p
     L.t41o_tx_create.restype = C.c_void_p
     L.t41o_tx_destroy.argtypes = [C.c_void_p]
     L.t41o_tx_reset.argtypes = [C.c_void_p]

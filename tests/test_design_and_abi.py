@@ -86,7 +86,7 @@ def test_design_rejects_bad_arguments(T):
     lib = T.load()
     p = T.default_params()
     n = lib.t41rx_coeff_blob_bytes(512)
-    assert n == 4 * (24 + 28 + 46 + 48 + 32 + 5 + 16 + 16 + 1024)  # 24-word header: 8 + t41rx_params padded to 16; 16 scalar slots
+    assert n == 4 * (32 + 28 + 46 + 48 + 32 + 5 + 16 + 16 + 1024)  # 32-word header: 8 + t41rx_params padded to 24; 16 scalar slots
     assert lib.t41rx_coeff_blob_bytes(500) == 0
     buf = (C.c_uint8 * n)()
     assert lib.t41rx_design_coeffs(C.byref(p), buf, n - 1) == _lib.ERR_ARG

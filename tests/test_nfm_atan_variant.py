@@ -123,9 +123,12 @@ def test_gpu_nfm_atan_variant_parity(built):
     rx.reset()
     parts = [rx.ProcessIQData(dI[:, k * L:(k + 1) * L].contiguous(), dQ[:, k * L:(k + 1) * L].contiguous()).cpu().numpy() for k in range(nfr)]
     assert np.array_equal(np.concatenate(parts, axis=1), got)
-    # the long FFT lengths have no kernel for it
-    rx4 = T.RxChain(2, T.default_params(fft_length=1024, mode=3, nfm_demod=1))
-    z = torch.zeros(2, 4096, device="cuda")
+    # the long FFT lengths have no kernel for it: refused where the parameters enter (create / set_params / set_coeffs),
+    # not at the first process call
     with pytest.raises(T.T41RxError) as e:
-        rx4.ProcessIQData(z, z)
-    assert e.value.status == _lib.ERR_UNSUPPORTED
+        T.RxChain(2, T.default_params(fft_length=1024, mode=3, nfm_demod=1))
+    assert e.value.status == _lib.ERR_ARG
+    rx4 = T.RxChain(2, T.default_params(fft_length=1024, mode=3, nfm_demod=0))
+    with pytest.raises(T.T41RxError) as e:
+        rx4.CalcFilters(nfm_demod=1)
+    assert e.value.status == _lib.ERR_ARG

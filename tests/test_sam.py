@@ -123,6 +123,35 @@ def test_gpu_sam_parity(built, agc):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("agc", [0, 2], ids=["agc-off", "agc-slow"])
+def test_gpu_sam_pull_in_bound(built, agc):
+    """The frames BEFORE lock, under a stated bound instead of being skipped.  The loop starts on the
+    filter's start-up transient (the phase detector divides rounding-level numbers and jumps by 2 pi where
+    pi / 2 is meant), so for about three frames two implementations follow different trajectories -- the
+    difference is of the order of the signal -- and then converge geometrically (measured on MI355X, 64
+    channels, difference normalised to the channel's locked audio level: 2.6, 1.1, 0.78, 0.09, 0.046, 6e-3,
+    3e-3, 4e-4, 2e-4, 3e-5, 1.3e-5, then the rounding floor ~1.3e-6; tools/sam_pullin_probe.py).  Bar:
+    frame f <= 20 x 2.5^-f of the locked level (a factor ~8 above the measured envelope), every frame
+    finite and no larger than the detector's own output range, and 1e-5 from frame 12 on."""
+    import t41_sdr_amd as T
+    nch, nfr = 64, 16
+    nco = siggen.nco_grid(nch, seed=21)
+    I, Q = siggen.make_am_carrier(nch, nfr * L, nco, seed=40 + agc)
+    kw = dict(KW, AGCMode=agc)
+    got, _ = _gpu_run(T, kw, nco, I, Q, [nfr])
+    ref = O.OracleBatch(O.default_params(**kw), np.asarray(nco, np.int32)).process(I, Q, nthreads=8)
+    assert np.isfinite(got).all()
+    lvl = np.abs(ref[:, LOCKED * L:]).max(axis=1, keepdims=True)
+    d = np.abs(got.astype(np.float64) - ref).reshape(nch, nfr, L).max(axis=2) / lvl
+    worst = d.max(axis=0)
+    for f in range(LOCKED):
+        assert worst[f] <= max(1e-5, 20.0 * 2.5 ** -f), (f, worst)
+    assert worst[LOCKED:].max() <= 1e-5, worst
+    # both are outputs of the same bounded detector: neither runs away during the pull-in
+    assert np.abs(got[:, :LOCKED * L]).max() <= 6.0 * max(np.abs(ref[:, :LOCKED * L]).max(), lvl.max())
+
+
+@pytest.mark.gpu
 def test_gpu_sam_split_and_state(built):
     """frames in one call or in several: bit-identical audio and PLL state; reset returns to power-on"""
     import t41_sdr_amd as T

@@ -12,6 +12,7 @@ mkdir -p "$OUT"
 python3 "$ROOT/tools/ablation_table.py" run --rounds 3 --frames 32 --reps 60 --out "$OUT/${TAG}_ablation_ssb.md" > "$OUT/${TAG}_ablation_run.log" 2>&1 || { echo "ablation run failed"; tail -5 "$OUT/${TAG}_ablation_run.log"; exit 1; }
 CSV="$OUT/${TAG}_ablation_stats.csv"
 echo '"build","Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs","StdDev"' > "$CSV"
+mkdir -p "$OUT/ablprof_$TAG"
 cd /tmp
 for V in product abl1 abl2 abl3 abl4 abl5 abl6 abl7 abl9; do
   if [ "$V" = product ]; then unset T41RX_LIB; else export T41RX_LIB="$ROOT/t41_sdr_amd/abl/libt41rx_$V.so"; [ -f "$T41RX_LIB" ] || continue; fi

@@ -16,6 +16,7 @@
 #include <string>
 #include <vector>
 
+#include "nr_kernels.hpp"
 #include "rx_internal.hpp"
 #include "rx_kernels.hpp"
 
@@ -44,6 +45,9 @@ struct t41rx_ctx {
   float *d_mid = nullptr, *d_aud24 = nullptr;
   int scratch_frames = 0;
   int nco_sel = 0;               // long FFT: which NcoState copy is current (flips with every process call)
+  // noise reduction / notch (Process.cpp:841-866): state of Xanr() and of the two spectral functions, window tables;
+  // allocated when a call first needs them
+  float *d_nr_anr = nullptr, *d_nr_spec = nullptr, *d_nr_tab = nullptr;
   // staging for t41rx_process_host
   float *d_in_i = nullptr, *d_in_q = nullptr, *d_out = nullptr;
   size_t staging_floats = 0;
@@ -233,6 +237,44 @@ int reset_state(t41rx_ctx *ctx) {
   HIP_TRY(hipMemcpy(ctx->d_state, h.data(), sizeof(float) * h.size(), hipMemcpyHostToDevice));
   ctx->nco_sel = 0;
   if (ctx->d_disp) HIP_TRY(hipMemset(ctx->d_disp, 0, sizeof(float) * kDispFloats * (size_t)ctx->nchan));
+  if (ctx->d_nr_anr) {  // InitializeDataArrays() + SpectralNoiseReductionInit() (T41_SDR.ino:479-504, 657)
+    std::vector<float> anr((size_t)kAnrStRows * (size_t)ctx->nchan), spec((size_t)kNrSpecFloats * (size_t)ctx->nchan);
+    nr_reset_anr(anr.data(), (size_t)ctx->nchan);
+    for (int c = 0; c < ctx->nchan; ++c) nr_reset_record(spec.data() + (size_t)kNrSpecFloats * (size_t)c);
+    HIP_TRY(hipMemcpy(ctx->d_nr_anr, anr.data(), sizeof(float) * anr.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->d_nr_spec, spec.data(), sizeof(float) * spec.size(), hipMemcpyHostToDevice));
+  }
+  return T41RX_OK;
+}
+
+// state and tables of the noise-reduction stages, on first use
+int ensure_nr(t41rx_ctx *ctx) {
+  if (ctx->d_nr_anr) return T41RX_OK;
+  float *anr = nullptr, *spec = nullptr, *tab = nullptr;
+  if (hipMalloc((void **)&anr, sizeof(float) * kAnrStRows * (size_t)ctx->nchan) != hipSuccess ||
+      hipMalloc((void **)&spec, sizeof(float) * kNrSpecFloats * (size_t)ctx->nchan) != hipSuccess ||
+      hipMalloc((void **)&tab, sizeof(float) * kNrTabFloats) != hipSuccess) {
+    (void)hipFree(anr);
+    (void)hipFree(spec);
+    (void)hipFree(tab);
+    return fail(T41RX_ERR_NOMEM, "noise-reduction state allocation failed");
+  }
+  float h[kNrTabFloats];
+  nr_make_tables(h);
+  std::vector<float> ha((size_t)kAnrStRows * (size_t)ctx->nchan), hs((size_t)kNrSpecFloats * (size_t)ctx->nchan);
+  nr_reset_anr(ha.data(), (size_t)ctx->nchan);
+  for (int c = 0; c < ctx->nchan; ++c) nr_reset_record(hs.data() + (size_t)kNrSpecFloats * (size_t)c);
+  if (hipMemcpy(tab, h, sizeof(h), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(anr, ha.data(), sizeof(float) * ha.size(), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(spec, hs.data(), sizeof(float) * hs.size(), hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipFree(anr);
+    (void)hipFree(spec);
+    (void)hipFree(tab);
+    return fail(T41RX_ERR_HIP, "noise-reduction state upload failed");
+  }
+  ctx->d_nr_anr = anr;
+  ctx->d_nr_spec = spec;
+  ctx->d_nr_tab = tab;
   return T41RX_OK;
 }
 
@@ -251,6 +293,9 @@ void free_ctx(t41rx_ctx *ctx) {
   (void)hipFree(ctx->d_pre);
   (void)hipFree(ctx->d_disp);
   (void)hipFree(ctx->d_win);
+  (void)hipFree(ctx->d_nr_anr);
+  (void)hipFree(ctx->d_nr_spec);
+  (void)hipFree(ctx->d_nr_tab);
   delete ctx;
 }
 
@@ -479,8 +524,14 @@ int process_device_impl(t41rx_ctx *ctx, const float *dI, const float *dQ, float 
   DeviceGuard g(ctx->device);
   if (!g.ok) return fail(T41RX_ERR_HIP, "hipSetDevice failed");
   const int seg = ctx->params.fft_length / 512;
-  if (seg > 1 && n_frames > ctx->scratch_frames) {
-    // scratch between the three kernels of the long-FFT pipeline (grown on demand, kept)
+  const bool nr_on = ctx->params.nrOptionSelect != 0 || ctx->params.ANR_notchOn != 0;  // (fft_length 512: params_valid)
+  if (nr_on && q15) return fail(T41RX_ERR_UNSUPPORTED, "noise reduction / notch are built for the f32 entry points");
+  if (nr_on) {
+    const int rc = ensure_nr(ctx);
+    if (rc != T41RX_OK) return rc;
+  }
+  if ((seg > 1 || nr_on) && n_frames > ctx->scratch_frames) {
+    // scratch between the kernels of the long-FFT pipeline / the noise-reduction pipeline (grown on demand, kept)
     HIP_TRY(hipStreamSynchronize((hipStream_t)hip_stream));
     (void)hipFree(ctx->d_mid);
     (void)hipFree(ctx->d_aud24);
@@ -550,8 +601,32 @@ int process_device_impl(t41rx_ctx *ctx, const float *dI, const float *dQ, float 
   a.dbg_demod = ctx->dbg_demod;
   a.spect = ctx->spect;
   a.spect_max = ctx->spect_max;
+  if (nr_on) a.aud_out = ctx->d_aud24;  // the fused kernel stops behind the demodulator
   hipError_t e = launch_rx(a, ctx->params.fft_length, ctx->params.mode, (hipStream_t)hip_stream);
   if (e != hipSuccess) return hip_fail(e, "kernel launch");
+  if (nr_on) {
+    // Process.cpp:841-866 on the call's audio @24 kS/s, then the interpolators, volume and stores (Process.cpp:917-937)
+    NrArgs n{};
+    n.aud = ctx->d_aud24;
+    n.anr = ctx->d_nr_anr;
+    n.spec = ctx->d_nr_spec;
+    n.tab_nr = ctx->d_nr_tab;
+    n.tab = ctx->d_tab;
+    n.nchan = ctx->nchan;
+    n.nframes = n_frames;
+    n.nr_option = ctx->params.nrOptionSelect;
+    n.notch = ctx->params.ANR_notchOn;
+    n.alpha = ctx->params.NR_alpha;
+    n.beta = ctx->params.NR_beta;
+    n.psi = ctx->params.NR_PSI;
+    nr_vad_range(ctx->params.FLoCut, ctx->params.FHiCut, &n.vad_lo, &n.vad_hi);
+    e = launch_nr(n, (hipStream_t)hip_stream);
+    if (e != hipSuccess) return hip_fail(e, "noise-reduction kernel launch");
+    a.aud_out = nullptr;
+    a.aud24 = ctx->d_aud24;
+    e = launch_back512(a, (hipStream_t)hip_stream);
+    if (e != hipSuccess) return hip_fail(e, "interpolator kernel launch");
+  }
   if (seg > 1) ctx->nco_sel ^= 1;  // the kernels wrote the other copy
   if (ctx->disp_spec) {
     DispArgs d{};

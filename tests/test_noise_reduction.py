@@ -156,3 +156,182 @@ def test_whole_path_with_nr_is_the_plain_path_plus_the_stage(built, kw):
     want = interp(want24) * scale
     err = siggen.block_rel_err(got[None], want[None].astype(np.float32), L)
     assert err[:, 1:].max() < 2e-5, err
+
+
+# ---- conditioning of the stages themselves (CPU): what a 3e-7 change of their input does to the ORACLE's output ----
+def _demod_audio(nfr, kw=None, seed=31, nco=7350):
+    I, Q = siggen.make_iq(1, nfr * L, [nco], mode=(kw or {}).get("mode", 0), seed=seed)
+    plain = O.OracleBatch(O.default_params(**(kw or {})), [nco])
+    demod = np.empty(nfr * D, np.float32)
+    for f in range(nfr):
+        plain.process(I[:, f * L:(f + 1) * L], Q[:, f * L:(f + 1) * L])
+        demod[f * D:(f + 1) * D] = plain.tap(0, O.TAP_DEMOD, D)
+    return demod
+
+
+def test_oracle_stage_conditioning(built):
+    """The tolerances of the GPU tests below are the stages' own conditioning, measured here on the oracle: the same
+    audio with an absolute perturbation of 1e-7 of its level (what the front ends of two f32 implementations differ by) gives
+      notch from power-on : ~1e-3 .. 1e-2 for tens of frames -- the filter starts adapting on the front end's start-up
+                            transient, where it divides by a power estimate of rounding-level samples; switched on
+                            once audio flows it stays at the 1e-5 level
+      Kim                 : grows to ~1e-5 .. 1e-4 (gain = 1 - M / E cancels where the noise is stationary)
+      spectral            : ~1e-5 typical, isolated frames up to 1e-2 (the smoothing width NN is an integer function of a power ratio)"""
+    rng = np.random.default_rng(8)
+    x = _demod_audio(40)
+    # absolute, like the difference between two f32 front ends: 1e-7 of the stream's level -- which is also the size of
+    # the first samples after power-on (the filters' start-up: 1e-7 .. 1e-5 for the first 30 samples)
+    xp = (x.astype(np.float64) + 1e-7 * np.abs(x).max() * rng.standard_normal(x.size)).astype(np.float32)
+    res = {}
+    for name, kw in (("notch", dict(ANR_notchOn=1)), ("kim", dict(nrOptionSelect=1)), ("spectral", dict(nrOptionSelect=2))):
+        a, _ = oracle_blocks(x, **kw)
+        b, _ = oracle_blocks(xp, **kw)
+        res[name] = rel(b, a)
+    # the notch switched on after 4 frames of flowing audio
+    lib, R = O.lib(), np.zeros(D, np.float32)
+    outs = []
+    for src in (x, xp):
+        s = lib.t41o_nr_create()
+        p = O.default_params(ANR_notchOn=1)
+        o = src.copy()
+        for b in range(4, 40):
+            blk = src[b * D:(b + 1) * D].copy()
+            lib.t41o_nr_block(s, C.byref(p), O.fptr(blk), O.fptr(R))
+            o[b * D:(b + 1) * D] = blk
+        outs.append(o)
+    res["notch-late"] = rel(outs[1], outs[0])
+    assert res["notch"].max() > 1e-4            # ill-conditioned from power-on ...
+    assert res["notch-late"].max() < 5e-5       # ... well-conditioned once audio flows
+    assert res["kim"].max() < 1e-3 and np.median(res["spectral"]) < 1e-4
+
+
+# ---- the HIP path ------------------------------------------------------------------------------------------------
+def _vol_scale(audioVolume=30):
+    x = np.float32(audioVolume) / np.float32(100.0)
+    ampl = np.float32(5) * x * x * x * x * x
+    return np.float32(8.0) * ampl  # DF * VolumeToAmplification(), Process.cpp:929, 955-967
+
+
+def _oracle_stage_and_interpolators(pre, kw):
+    """the oracle's stage (Process.cpp:841-866) and interpolators (Process.cpp:917-931) on given 24 kS/s audio, per channel"""
+    lib = O.lib()
+    p = O.default_params(**kw)
+    c = O.design(p)
+    nch, n = pre.shape
+    out = np.empty((nch, 8 * n), np.float32)
+    R = np.zeros(D, np.float32)
+    scale = _vol_scale(p.audioVolume)
+    for ch in range(nch):
+        s = lib.t41o_nr_create()
+        st1, st2 = np.zeros(23 + D, np.float32), np.zeros(7 + 2 * D, np.float32)
+        mid, hi = np.empty(2 * D, np.float32), np.empty(8 * D, np.float32)
+        for b in range(n // D):
+            blk = pre[ch, b * D:(b + 1) * D].copy()
+            lib.t41o_nr_block(s, C.byref(p), O.fptr(blk), O.fptr(R))
+            lib.t41o_fir_interpolate_f32(c.int1, 48, 2, O.fptr(st1), O.fptr(blk), O.fptr(mid), D)
+            lib.t41o_fir_interpolate_f32(c.int2, 32, 4, O.fptr(st2), O.fptr(mid), O.fptr(hi), 2 * D)
+            out[ch, b * L:(b + 1) * L] = hi * scale
+        lib.t41o_nr_destroy(s)
+    return out
+
+
+NR_CASES = {
+    # name: (params, tolerance of the stage in isolation, how it is applied)
+    "notch": (dict(ANR_notchOn=1), 3e-6, "max"),        # lane-per-channel, the reference's operations in its order: only the
+    "lms": (dict(nrOptionSelect=3), 3e-6, "max"),       # interpolators' roundings differ
+    "lms+notch": (dict(nrOptionSelect=3, ANR_notchOn=1), 3e-6, "max"),
+    "kim": (dict(nrOptionSelect=1), 1e-4, "max"),       # another FFT and summation order: the stage's conditioning (test above)
+    "kim+notch": (dict(nrOptionSelect=1, ANR_notchOn=1), 2e-3, "max"),   # ... fed to the notch from power-on
+    "spectral": (dict(nrOptionSelect=2), 1e-3, "most"),
+    "spectral-am-agc": (dict(nrOptionSelect=2, mode=2, FLoCut=-3000, FHiCut=3000, AGCMode=2), 1e-3, "most"),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(NR_CASES))
+def test_gpu_stage_in_isolation(built, name):
+    """The stage and what follows it, on IDENTICAL input: the HIP path's own demodulated audio (the stage tap in front
+    of it) through the oracle's stage and interpolators must give the HIP path's output.  70 channels = one full wave
+    of the lane-per-channel kernel and a ragged one; three calls."""
+    import torch
+    import t41_sdr_amd as T
+    kw, tol, how = NR_CASES[name]
+    nch, nfr = 70, 36
+    nco = siggen.nco_grid(nch, seed=5)
+    I, Q = siggen.make_iq(nch, nfr * L, nco, mode=kw.get("mode", 0), seed=50)
+    rx = T.RxChain(nch, T.default_params(**kw), NCOFreq=nco)
+    dI, dQ = torch.from_numpy(I).cuda(), torch.from_numpy(Q).cuda()
+    got, pre, pos = [], [], 0
+    for n in (1, 15, 20):
+        tap = torch.zeros(nch, n * D, device="cuda")
+        rx.set_debug_taps(demod=tap)
+        got.append(rx.ProcessIQData(dI[:, pos * L:(pos + n) * L].contiguous(), dQ[:, pos * L:(pos + n) * L].contiguous()))
+        pre.append(tap)
+        pos += n
+    got, pre = torch.cat(got, dim=1).cpu().numpy(), torch.cat(pre, dim=1).cpu().numpy()
+    assert np.isfinite(got).all()
+    want = _oracle_stage_and_interpolators(pre, kw)
+    e = siggen.block_rel_err(got, want, L)
+    if how == "max":
+        assert e.max() <= tol, "worst %.3e at %s" % (e.max(), np.unravel_index(e.argmax(), e.shape))
+    else:  # discontinuous gain rule: nearly every frame, and the typical frame far below
+        assert (e < tol).mean() > 0.985 and np.median(e) < 2e-5, ((e < tol).mean(), np.median(e), e.max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["notch-late", "lms", "kim", "spectral"])
+def test_gpu_whole_path_with_nr(built, name):
+    """ProcessIQData() with a stage on against the oracle, whole path.  The notch is switched on after four frames, as
+    from the front panel (ButtonProc.cpp:433): from power-on it adapts on the start-up transient (conditioning test above)."""
+    import torch
+    import t41_sdr_amd as T
+    kw = dict(NR_CASES[name.replace("-late", "")][0])
+    late = name.endswith("-late")
+    nch, nfr = 12, 28
+    nco = siggen.nco_grid(nch, seed=6)
+    I, Q = siggen.make_iq(nch, nfr * L, nco, mode=0, seed=60)
+    start = dict(kw, ANR_notchOn=0) if late else kw
+    rx = T.RxChain(nch, T.default_params(**start), NCOFreq=nco)
+    ob = O.OracleBatch(O.default_params(**start), np.asarray(nco, np.int32))
+    dI, dQ = torch.from_numpy(I).cuda(), torch.from_numpy(Q).cuda()
+    a = rx.ProcessIQData(dI[:, :4 * L].contiguous(), dQ[:, :4 * L].contiguous()).cpu().numpy()
+    ra = ob.process(I[:, :4 * L], Q[:, :4 * L])
+    if late:
+        rx.CalcFilters(ANR_notchOn=1)
+        ob.p.ANR_notchOn = 1
+    b = rx.ProcessIQData(dI[:, 4 * L:].contiguous(), dQ[:, 4 * L:].contiguous()).cpu().numpy()
+    rb = ob.process(I[:, 4 * L:], Q[:, 4 * L:])
+    e = siggen.block_rel_err(np.concatenate([a, b], axis=1), np.concatenate([ra, rb], axis=1), L)
+    tol = {"notch-late": 5e-5, "lms": 1e-5, "kim": 1e-4}.get(name)
+    if tol is not None:
+        assert e.max() <= tol, e.max(axis=0)
+    else:
+        assert (e < 1e-3).mean() > 0.97 and np.median(e) < 2e-5, ((e < 1e-3).mean(), np.median(e))
+
+
+@pytest.mark.gpu
+def test_gpu_nr_split_reset_and_refusals(built):
+    import torch
+    import t41_sdr_amd as T
+    import t41_sdr_amd._lib as lib
+    nch, nfr = 9, 12
+    nco = siggen.nco_grid(nch, seed=7)
+    I, Q = siggen.make_iq(nch, nfr * L, nco, mode=0, seed=70)
+    dI, dQ = torch.from_numpy(I).cuda(), torch.from_numpy(Q).cuda()
+    for kw in (dict(nrOptionSelect=1, ANR_notchOn=1), dict(nrOptionSelect=2), dict(nrOptionSelect=3, ANR_notchOn=1)):
+        rx = T.RxChain(nch, T.default_params(**kw), NCOFreq=nco)
+        whole = rx.ProcessIQData(dI, dQ).cpu().numpy()
+        rx.reset()  # power-on again: InitializeDataArrays() + SpectralNoiseReductionInit()
+        parts = [rx.ProcessIQData(dI[:, a * L:b * L].contiguous(), dQ[:, a * L:b * L].contiguous()).cpu().numpy()
+                 for a, b in ((0, 1), (1, 6), (6, 12))]
+        assert np.array_equal(np.concatenate(parts, axis=1), whole)
+    # q15 entry points, long FFT lengths, a pass band the spectral function's smoothing runs out of
+    rx = T.RxChain(2, T.default_params(ANR_notchOn=1))
+    z = torch.zeros(2, L, dtype=torch.int16, device="cuda")
+    with pytest.raises(T.T41RxError) as e:
+        rx.ProcessIQData_q15(z, z)
+    assert e.value.status == lib.ERR_UNSUPPORTED
+    for bad in (dict(fft_length=1024, ANR_notchOn=1), dict(nrOptionSelect=2, FLoCut=400, FHiCut=600), dict(nrOptionSelect=4)):
+        with pytest.raises(T.T41RxError) as e:
+            T.RxChain(2, T.default_params(**bad))
+        assert e.value.status == lib.ERR_ARG

@@ -50,7 +50,7 @@ extern "C" {
 #define T41RX_DEMOD_LSB 1
 #define T41RX_DEMOD_AM 2
 #define T41RX_DEMOD_NFM 3
-#define T41RX_DEMOD_SAM 8 /* synchronous AM, AMDecodeSAM() Demod.cpp:40-139 (SDT.h:67); fft_length 512, f32 samples */
+#define T41RX_DEMOD_SAM 8 /* synchronous AM, AMDecodeSAM() Demod.cpp:40-139 (SDT.h:67); fft_length 512 */
 
 /* xmtMode, SDT.h:48-50 (only affects the CW side-tone offset of the NCO, Freq_Shift.cpp:108-120) */
 #define T41RX_SSB_MODE 0

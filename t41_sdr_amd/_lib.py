@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("T41RX_LIB", os.path.join(_HERE, "libt41rx.so"))  # ov
 T41RX_OK = 0
 ERR_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_NOMEM, ERR_STATE = -1, -2, -3, -4, -5
 DEMOD_USB, DEMOD_LSB, DEMOD_AM, DEMOD_NFM = 0, 1, 2, 3
-DEMOD_SAM = 8  # synchronous AM (SDT.h:67), fft_length 512, f32 samples
+DEMOD_SAM = 8  # synchronous AM (SDT.h:67), fft_length 512
 SSB_MODE, CW_MODE, DATA_MODE = 0, 1, 2
 
 

@@ -571,7 +571,6 @@ int process_device_impl(t41rx_ctx *ctx, const float *dI, const float *dQ, float 
     a.plain = ((iq_on ? gi == -1.0f : gi == 1.0f) && sc[kScBandGain] == 1.0f && (!iq_on || sc[kScIqPhase] == 0.0f)) ? 1 : 0;
   }
   a.q15 = q15 ? 1 : 0;
-  if (q15 && ctx->params.mode == T41RX_DEMOD_SAM) return fail(T41RX_ERR_UNSUPPORTED, "SAM is built for the f32 entry points");
   a.nco_rd = ctx->nco_sel;
   a.nfm_atan = (ctx->params.mode == T41RX_DEMOD_NFM && ctx->params.nfm_demod == 1) ? 1 : 0;
   if (a.nfm_atan && seg > 1) return fail(T41RX_ERR_UNSUPPORTED, "nfm_demod = 1 is built for fft_length 512");

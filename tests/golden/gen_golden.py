@@ -38,10 +38,17 @@ CASES = {
     "usb_q15": (dict(mode=0, FLoCut=200, FHiCut=3000, audioVolume=100), [5000, -12350]),
     # synchronous AM (Demod.cpp:40-139): long enough for the PLL to lock (tests compare the GPU from frame 12 on)
     "sam": (dict(mode=8, FLoCut=-3000, FHiCut=3000), [1000, -20000]),
+    # the optional stages behind the demodulator (Process.cpp:841-866, Noise.cpp): Kim, spectral (20 half-blocks of
+    # initialisation first), LMS + automatic notch (from power-on the notch is ill-conditioned: the GPU test only
+    # requires finite output for it, see tests/test_noise_reduction.py::test_oracle_stage_conditioning)
+    "usb_nr_kim": (dict(mode=0, FLoCut=200, FHiCut=3000, nrOptionSelect=1), [5000, -12350]),
+    "usb_nr_spectral": (dict(mode=0, FLoCut=200, FHiCut=3000, nrOptionSelect=2), [5000, -12350]),
+    "usb_nr_lms_notch": (dict(mode=0, FLoCut=200, FHiCut=3000, nrOptionSelect=3, ANR_notchOn=1), [5000, -12350]),
 }
 FADE = [(0.3, 2.0), (0.3, 0.05), (0.4, 1.2)]  # AGC cases
 NFRAMES_AGC = 10
 NFRAMES_SAM = 14
+NFRAMES_NR = 16
 NFRAMES = 3
 L = 2048
 
@@ -57,6 +64,8 @@ def make_inputs(name, kw, nco):
         return siggen.fade(I, Q, FADE)
     nch = len(nco)
     seed = 0x5441315F + sum(ord(c) for c in name)
+    if kw.get("nrOptionSelect", 0) or kw.get("ANR_notchOn", 0):
+        return siggen.make_iq(nch, NFRAMES_NR * L, np.asarray(nco), mode=kw["mode"], seed=seed)
     if kw["mode"] == 8:
         return siggen.make_am_carrier(nch, NFRAMES_SAM * L, np.asarray(nco), seed=seed)
     if kw["mode"] == 3:  # FM-modulated carriers so the discriminator sees a real signal

@@ -177,11 +177,32 @@ def test_gpu_sam_refusals(built):
     with pytest.raises(T.T41RxError) as e:
         T.RxChain(2, T.default_params(**dict(KW, fft_length=1024)))
     assert e.value.status == _lib.ERR_ARG
-    rx = T.RxChain(2, T.default_params(**KW))
-    z = torch.zeros(2, L, dtype=torch.int16, device="cuda")
-    with pytest.raises(T.T41RxError) as e:
-        rx.ProcessIQData_q15(z, z)
-    assert e.value.status == _lib.ERR_UNSUPPORTED
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("agc", [0, 1], ids=["agc-off", "agc-long"])
+def test_gpu_sam_q15(built, agc):
+    """the firmware only ever feeds q15 samples (Process.cpp:107-108, 936): the synchronous detector on the q15 entry
+    points = bit for bit its f32 entry point on the converted samples, then arm_float_to_q15; against the oracle's
+    q15 path once locked"""
+    import torch
+    import t41_sdr_amd as T
+    nch, nfr = 6, 18
+    kw = dict(KW, AGCMode=agc, audioVolume=60)
+    nco = siggen.nco_grid(nch, seed=23)
+    I, Q = siggen.make_am_carrier(nch, nfr * L, nco, seed=91)
+    qI = np.clip(np.round(I * 32768.0), -32768, 32767).astype(np.int16)
+    qQ = np.clip(np.round(Q * 32768.0), -32768, 32767).astype(np.int16)
+    rx = T.RxChain(nch, T.default_params(**kw), NCOFreq=nco)
+    got = rx.ProcessIQData_q15(torch.from_numpy(qQ).cuda(), torch.from_numpy(qI).cuda()).cpu().numpy()  # L queue = Q, R queue = I
+    rx.reset()
+    f = rx.ProcessIQData(torch.from_numpy(qI.astype(np.float32) / np.float32(32768)).cuda(),
+                         torch.from_numpy(qQ.astype(np.float32) / np.float32(32768)).cuda()).cpu().numpy()
+    want = np.clip(np.trunc(f.astype(np.float64) * 32768.0), -32768, 32767).astype(np.int16)
+    assert np.array_equal(got, want) and np.abs(got[:, LOCKED * L:]).max() > 300
+    ref = O.OracleBatch(O.default_params(**kw), np.asarray(nco, np.int32)).process_q15(qQ, qI)
+    d = np.abs(got.astype(np.int32) - ref.astype(np.int32))[:, LOCKED * L:]
+    assert d.max() <= 1 + np.ceil(1e-5 * np.abs(ref.astype(np.int32)).max()), d.max()
 
 
 @pytest.mark.gpu

@@ -69,7 +69,8 @@ WORKLOADS = {
 BYTES_PER_SAMPLE = 12.0     # 2 x f32 in + 1 x f32 out per input complex sample
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 DEFAULT_FRAMES = 32         # consecutive frames per channel per launch (>= 100 consecutive frames per run)
-KERNEL_SOURCES = ("t41_sdr_amd/csrc/rx_kernels.hip", "t41_sdr_amd/csrc/rx_kernels.hpp", "t41_sdr_amd/csrc/rx_internal.hpp")
+KERNEL_SOURCES = ("t41_sdr_amd/csrc/rx_kernels.hip", "t41_sdr_amd/csrc/rx_kernels.hpp", "t41_sdr_amd/csrc/rx_internal.hpp",
+                  "t41_sdr_amd/csrc/wave_fft.hpp")
 
 
 def kernel_source_hash():

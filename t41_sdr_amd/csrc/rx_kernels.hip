@@ -123,6 +123,10 @@ __device__ __forceinline__ void fft512_ldstw(cf (&v)[8], const cf *tw1l, const c
     const cf w = tw1l[64 * (q - 1)];
     v[q] = INV ? cmulc(v[q], w) : cmul(v[q], w);
   }
+#if T41RX_FFT_X1_PERM
+  fft_exchange1_perm(v);
+  mid();
+#else
   wave_sync();
 #pragma unroll
   for (int q = 0; q < 8; ++q) xb[q * kFftRow + lane] = v[q];
@@ -133,6 +137,7 @@ __device__ __forceinline__ void fft512_ldstw(cf (&v)[8], const cf *tw1l, const c
 #pragma unroll
     for (int k2 = 0; k2 < 8; ++k2) v[k2] = xb[q * kFftRow + l1 + 8 * k2];
   }
+#endif
   dft8<INV>(v);
 #pragma unroll
   for (int q = 1; q < 8; ++q) {
@@ -170,6 +175,10 @@ __device__ __forceinline__ void fft512_ldstw_x2(cf (&v)[8], cf (&u)[8], const cf
     v[q] = INV ? cmulc(v[q], w) : cmul(v[q], w);
     u[q] = INV ? cmulc(u[q], w) : cmul(u[q], w);
   }
+#if T41RX_FFT_X1_PERM
+  fft_exchange1_perm(v);
+  fft_exchange1_perm(u);
+#else
   wave_sync();
 #pragma unroll
   for (int q = 0; q < 8; ++q) xv[q * kFftRow + lane] = v[q];
@@ -180,6 +189,7 @@ __device__ __forceinline__ void fft512_ldstw_x2(cf (&v)[8], cf (&u)[8], const cf
   for (int k2 = 0; k2 < 8; ++k2) v[k2] = xv[q3 * kFftRow + l1 + 8 * k2];
 #pragma unroll
   for (int k2 = 0; k2 < 8; ++k2) u[k2] = xu[q3 * kFftRow + l1 + 8 * k2];
+#endif
   dft8<INV>(v);
   dft8<INV>(u);
 #pragma unroll

@@ -92,6 +92,61 @@ constexpr int kFftRow = 72;
 // pairs (plain 8 l1 is 4-way conflicted: 8 l1 mod 16 has two values); rows stay disjoint (max 69).
 __device__ __forceinline__ constexpr int fft_x2(int l1) { return 8 * l1 + (l1 & 6); }
 
+// The first exchange of the 512-point transform -- register index <-> lane bits 3..5, three independent bit
+// swaps -- runs inside the VALU instead of through LDS: v_permlane32_swap (bit 5), v_permlane16_swap (bit 4), and
+// for bit 3 a pair of bank-masked DPP row shifts by 8.  40 VALU instructions per transform in place of 8
+// ds_write_b64 + 8 ds_read_b64 (+ 3 for addresses) and two LDS ordering points.  Measured on MI355X in the fused
+// FFT_LENGTH 512 kernel (interleaved rounds, tools/ablation_table.py, profiles/r03_ablation_ssb.md): 0.9 % faster
+// than the LDS form (-DT41RX_FFT_X1_PERM=0) -- the kernel is co-limited by VALU and LDS, and the LDS relief wins.
+// The second exchange moves lane bits 0..2 AND swaps the lane's two octal digits; the same trade costs ~85 VALU
+// instructions there (no swap instruction below 16 lanes) and stays in LDS.
+#ifndef T41RX_FFT_X1_PERM
+#define T41RX_FFT_X1_PERM 1
+#endif
+__device__ __forceinline__ void lane_swap32(float &a, float &b) {  // lanes 32..63 of a <-> lanes 0..31 of b
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r[0]);
+  b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void lane_swap16(float &a, float &b) {  // odd 16-lane rows of a <-> even rows of b
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r[0]);
+  b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void lane_swap8(float &a, float &b) {  // lanes 8..15 of every row of a <-> lanes 0..7 of b
+  const float t = b;
+  b = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(b), __float_as_int(a), 0x108 /* row_shl:8 */, 0xf, 0x3, false));
+  a = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(a), __float_as_int(t), 0x118 /* row_shr:8 */, 0xf, 0xc, false));
+}
+// (reg q, lane l1 + 8 k2) -> (reg k2, lane l1 + 8 q)
+__device__ __forceinline__ void fft_exchange1_perm(cf (&v)[8]) {
+  float re[8], im[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    re[q] = v[q].x;
+    im[q] = v[q].y;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    lane_swap32(re[q], re[q + 4]);
+    lane_swap32(im[q], im[q + 4]);
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    if (q & 2) continue;
+    lane_swap16(re[q], re[q + 2]);
+    lane_swap16(im[q], im[q + 2]);
+  }
+#pragma unroll
+  for (int q = 0; q < 8; q += 2) {
+    lane_swap8(re[q], re[q + 1]);
+    lane_swap8(im[q], im[q + 1]);
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) v[q] = cf{re[q], im[q]};
+}
+
+
 // 512-point complex FFT held as 8 points per lane: lane l register r <-> element l + 64 r,
 // on input AND output (natural order both ways, no bit-reversal pass).
 //   stage 1: DFT8 over r (stride 64), twiddle W512^(l q)
@@ -106,6 +161,9 @@ __device__ __forceinline__ void fft512(cf (&v)[8], const cf (&tw1)[7], const cf 
 #pragma unroll
   for (int q = 1; q < 8; ++q) v[q] = INV ? cmulc(v[q], tw1[q - 1]) : cmul(v[q], tw1[q - 1]);
   // exchange 1: (reg q, lane l1 + 8 k2) -> (reg k2, lane l1 + 8 q)
+#if T41RX_FFT_X1_PERM
+  fft_exchange1_perm(v);
+#else
   wave_sync();
 #pragma unroll
   for (int q = 0; q < 8; ++q) xb[q * kFftRow + lane] = v[q];
@@ -115,6 +173,7 @@ __device__ __forceinline__ void fft512(cf (&v)[8], const cf (&tw1)[7], const cf 
 #pragma unroll
     for (int k2 = 0; k2 < 8; ++k2) v[k2] = xb[q * kFftRow + l1 + 8 * k2];
   }
+#endif
   dft8<INV>(v);
 #pragma unroll
   for (int q = 1; q < 8; ++q) v[q] = INV ? cmulc(v[q], tw2[q - 1]) : cmul(v[q], tw2[q - 1]);

@@ -14,7 +14,7 @@ CSV="$OUT/${TAG}_ablation_stats.csv"
 echo '"build","Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs","StdDev"' > "$CSV"
 mkdir -p "$OUT/ablprof_$TAG"
 cd /tmp
-for V in product abl1 abl2 abl3 abl4 abl5 abl6 abl7 abl9; do
+for V in product abl1 abl2 abl3 abl4 abl5 abl6 abl7 abl9 x1lds; do
   if [ "$V" = product ]; then unset T41RX_LIB; else export T41RX_LIB="$ROOT/t41_sdr_amd/abl/libt41rx_$V.so"; [ -f "$T41RX_LIB" ] || continue; fi
   D="$OUT/ablprof_$TAG/$V"
   timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$D" -o t -- python3 "$ROOT/tools/ablation_table.py" one $V --frames 32 --reps 30 > "$D.log" 2>&1 || { echo "trace $V failed"; continue; }

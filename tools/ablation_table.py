@@ -33,6 +33,9 @@ VARIANTS = [
     ("abl6", 6, "... and without the DC high-pass"),
     ("abl7", 7, "memory only: loads, LDS staging, 1-KiB stores; no arithmetic"),
     ("abl9", 9, "arithmetic only: every wave on the same 16 channels' buffers (cache-resident I/O)"),
+    # a full kernel (correct outputs), not an ablation: the 512-point transforms' first exchange through LDS, as in
+    # round 2, instead of inside the VALU (v_permlane32_swap / v_permlane16_swap / DPP; wave_fft.hpp: T41RX_FFT_X1_PERM)
+    ("x1lds", "-DT41RX_FFT_X1_PERM=0", "product with the FFTs' first exchange through LDS (round 2's form) instead of v_permlane*_swap + DPP"),
 ]
 L = 2048
 ALG_BYTES_PER_FRAME = 12 * 4096 * L
@@ -47,7 +50,8 @@ def build():
         if n is None:
             continue
         print("building", name, flush=True)
-        subprocess.check_call([os.path.join(ROOT, "tools", "build_variant.sh"), name, "-DT41RX_ABLATE=%d" % n])
+        flag = n if isinstance(n, str) else "-DT41RX_ABLATE=%d" % n
+        subprocess.check_call([os.path.join(ROOT, "tools", "build_variant.sh"), name, flag])
 
 
 def one(frames, reps):

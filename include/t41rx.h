@@ -81,7 +81,7 @@ typedef struct t41rx_params {
                                       2 pi for pi / 2 as written) + limiter + deemphasis_nfm_ff applied block-wise
                                       (Demod.cpp:324-344, Process.cpp:734-735).  fft_length 512 only. */
   /* The optional stages between the demodulator and the interpolators, Process.cpp:841-866 (all off in the firmware's
-   * defaults).  fft_length 512, f32 entry points; the functions are written for blocks of 256 audio samples. */
+   * defaults).  fft_length 512; the functions are written for blocks of 256 audio samples. */
   int32_t nrOptionSelect;          /* gwv.cpp:23: 0 off; 1 Kim1_NR() (Noise.cpp:108-313) then x30; 2 SpectralNoiseReduction()
                                       (Noise.cpp:379-655); 3 Xanr() as LMS noise reduction (Noise.cpp:322-370) then x1.5 --
                                       as written the call site scales Xanr()'s INPUT, so 3 only changes the gain (and advances

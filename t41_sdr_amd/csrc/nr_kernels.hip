@@ -40,20 +40,27 @@ constexpr size_t kAnrLdsBytes = (size_t)(kAnrTile + 256) * kAnrRow * sizeof(floa
 // One pass of Noise.cpp:331-369 over the 256 samples in T[kAnrHist ..] for this lane's channel.
 // out (may be null): O tile.
 template <bool NOTCH>
-__device__ __forceinline__ void anr_pass(const float *T, float *O, float (&w)[kAnrTaps], float &lidx, float &ngamma, int lane) {
+__device__ __forceinline__ void anr_pass(const float *T, float *O, f2 (&w)[kAnrTaps / 2], float &lidx, float &ngamma, int lane) {
 #pragma clang fp contract(off)
   const float ANR_den_mult = 6.25e-10, ANR_gamma = 0.1, ANR_lidx_min = 120.0, ANR_lidx_max = 200.0;
   const float ANR_lincr = 1.0, ANR_ldecr = 3.0, ANR_two_mu = 0.0001;
   for (int i = 0; i < 256; ++i) {
     const float *row = T + i * kAnrRow + lane;
     const float d_in = row[kAnrHist * kAnrRow];  // ANR_d[ANR_in_idx]
-    float dj[kAnrTaps];
+    // (two taps per multiply instruction -- v_pk_mul_f32 rounds each product exactly like the scalar multiply -- and the
+    // sums accumulated one product at a time in tap order: the reference's roundings, fewer instructions)
+    // A register pair holds taps (j + 1, j) in (.x, .y): the window's rows ascend in time, i.e. descend in j, so one
+    // ds_read2_b32 fills a pair without a move.
+    f2 dj[kAnrTaps / 2];
     float y = 0, sigma = 0;
 #pragma unroll
-    for (int j = 0; j < kAnrTaps; ++j) {  // idx = in_idx + j + ANR_delay: the sample written j + 16 steps ago
-      dj[j] = row[(kAnrTaps - 1 - j) * kAnrRow];
-      y += w[j] * dj[j];
-      sigma += dj[j] * dj[j];
+    for (int j = 0; j < kAnrTaps; j += 2) {  // idx = in_idx + j + ANR_delay: the sample written j + 16 steps ago
+      dj[j / 2] = f2{row[(kAnrTaps - 2 - j) * kAnrRow], row[(kAnrTaps - 1 - j) * kAnrRow]};
+      const f2 p = w[j / 2] * dj[j / 2], q = dj[j / 2] * dj[j / 2];
+      y += p.y;
+      sigma += q.y;
+      y += p.x;
+      sigma += q.x;
     }
     const float inv_sigp = (float)(1.0 / ((double)sigma + 1e-10));
     const float error = d_in - y;
@@ -75,7 +82,7 @@ __device__ __forceinline__ void anr_pass(const float *T, float *O, float (&w)[kA
     const float c0 = (float)(1.0 - (double)(ANR_two_mu * ngamma));
     const float c1 = ANR_two_mu * error * inv_sigp;
 #pragma unroll
-    for (int j = 0; j < kAnrTaps; ++j) w[j] = c0 * w[j] + c1 * dj[j];
+    for (int j = 0; j < kAnrTaps / 2; ++j) w[j] = splat(c0) * w[j] + splat(c1) * dj[j];
   }
 }
 
@@ -88,9 +95,9 @@ __global__ __launch_bounds__(64, 1) void anr_kernel(const NrArgs a) {
   const int nlive = (a.nchan - ch0 < 64) ? a.nchan - ch0 : 64;
   const int ch = ch0 + (lane < nlive ? lane : nlive - 1);  // dead lanes shadow the last live channel (their stores are skipped)
   const size_t nch = (size_t)a.nchan;
-  float w[kAnrTaps];
+  f2 w[kAnrTaps / 2];  // ANR_w, two taps per register pair: (.x, .y) = taps (2 j + 1, 2 j), see anr_pass
 #pragma unroll
-  for (int j = 0; j < kAnrTaps; ++j) w[j] = a.anr[(size_t)(kAnrStW + j) * nch + ch];
+  for (int j = 0; j < kAnrTaps / 2; ++j) w[j] = f2{a.anr[(size_t)(kAnrStW + 2 * j + 1) * nch + ch], a.anr[(size_t)(kAnrStW + 2 * j) * nch + ch]};
   for (int r = 0; r < kAnrHist; ++r) T[r * kAnrRow + lane] = a.anr[(size_t)(kAnrStHist + r) * nch + ch];
   float lidx = a.anr[(size_t)kAnrStLidx * nch + ch], ngamma = a.anr[(size_t)kAnrStNgamma * nch + ch];
   for (int f = 0; f < a.nframes; ++f) {
@@ -128,7 +135,10 @@ __global__ __launch_bounds__(64, 1) void anr_kernel(const NrArgs a) {
   }
   if (lane < nlive) {
 #pragma unroll
-    for (int j = 0; j < kAnrTaps; ++j) a.anr[(size_t)(kAnrStW + j) * nch + ch] = w[j];
+    for (int j = 0; j < kAnrTaps / 2; ++j) {
+      a.anr[(size_t)(kAnrStW + 2 * j + 1) * nch + ch] = w[j].x;
+      a.anr[(size_t)(kAnrStW + 2 * j) * nch + ch] = w[j].y;
+    }
     for (int r = 0; r < kAnrHist; ++r) a.anr[(size_t)(kAnrStHist + r) * nch + ch] = T[r * kAnrRow + lane];
     a.anr[(size_t)kAnrStLidx * nch + ch] = lidx;
     a.anr[(size_t)kAnrStNgamma * nch + ch] = ngamma;
@@ -138,10 +148,16 @@ __global__ __launch_bounds__(64, 1) void anr_kernel(const NrArgs a) {
 // ------------------------------------------------------------------------------------------
 // Kim1_NR() / SpectralNoiseReduction(), one wave per channel
 // ------------------------------------------------------------------------------------------
+// sum over the wave, the same value in every lane: an inclusive scan inside the VALU (four row shifts, two row
+// broadcasts: DPP, no LDS round trips -- the spectral function's gain loop calls this once per bin) and lane 63's total
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
-  return v;
+  v += dpp_f<kDppRowShr1, 0xf, true>(0.0f, v);
+  v += dpp_f<kDppRowShr2, 0xf, true>(0.0f, v);
+  v += dpp_f<kDppRowShr4, 0xf, true>(0.0f, v);
+  v += dpp_f<kDppRowShr8, 0xf, true>(0.0f, v);
+  v += dpp_f<kDppRowBcast15, 0xa, false>(0.0f, v);
+  v += dpp_f<kDppRowBcast31, 0xc, false>(0.0f, v);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 template <int KIND>
@@ -153,7 +169,7 @@ __global__ __launch_bounds__(64) void nrspec_kernel(const NrArgs a) {
   __shared__ cf W0[129], W1[129];   // weighted, conjugate-symmetrised spectra of the two frames, bins 0..128
   __shared__ float Y0[256], Y1[256];
   __shared__ float Gb[130];         // gains with one pad either side: Gb[1 + i]
-  __shared__ float Xs[3][128], Es[15][128];
+  __shared__ float Xs[KIND == 1 ? 3 : 1][128], Es[KIND == 1 ? 15 : 1][128];  // Kim1_NR()'s frame histories
   __shared__ float Gts1[128], Gts0[128], Gst[128], Lout[128], Nest[128], Pslp[128], Xt[128], Hk[128];
   const int lane = threadIdx.x;
   const int ch = blockIdx.x;
@@ -168,8 +184,10 @@ __global__ __launch_bounds__(64) void nrspec_kernel(const NrArgs a) {
     tw2[q] = tab[kTabTw2 + 64 * q + lane];
   }
   // ---- the channel's record -> LDS
-  for (int i = lane; i < 3 * 128; i += 64) (&Xs[0][0])[i] = st[kNrX + i];
-  for (int i = lane; i < 15 * 128; i += 64) (&Es[0][0])[i] = st[kNrE + i];
+  if (KIND == 1) {
+    for (int i = lane; i < 3 * 128; i += 64) (&Xs[0][0])[i] = st[kNrX + i];
+    for (int i = lane; i < 15 * 128; i += 64) (&Es[0][0])[i] = st[kNrE + i];
+  }
   for (int i = lane; i < 128; i += 64) {
     Gts1[i] = st[kNrGts1 + i];
     Gts0[i] = st[kNrGts0 + i];
@@ -326,6 +344,15 @@ __global__ __launch_bounds__(64) void nrspec_kernel(const NrArgs a) {
             post[r] = (float)fmax(fmin((double)(x / xt), 1000.0), (double)snr_prio_min);
             prio[r] = (float)fmax((double)(NR_alpha * Hk[i]) + (1.0 - (double)NR_alpha) * fmax((double)post[r] - 1.0, 0.0), 0.0);
           }
+          // the gain each bin receives in its own pass of the loop below depends on its two SNRs alone (Noise.cpp:531-535):
+          // computed here for both of the lane's bins, so that the bin-by-bin loop only moves values
+          float gnew[2], hknew[2];
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            const float vv = (float)((double)(prio[r] * post[r]) / (1.0 + (double)prio[r]));
+            gnew[r] = (float)(1.0 / (double)post[r] * (double)sqrtf((float)(0.7212 * (double)vv + (double)(vv * vv))));
+            hknew[r] = post[r] * gnew[r] * gnew[r];
+          }
           __syncthreads();
           // pre_power: the same sum in every pass of the loop below
           float pre_part = 0.0f;
@@ -337,12 +364,8 @@ __global__ __launch_bounds__(64) void nrspec_kernel(const NrArgs a) {
           const float pre_power = wave_sum(pre_part);
           for (int i = lo; i < hi; ++i) {  // Noise.cpp:529-588: the musical-noise treatment runs inside this loop
             if (lane == (i & 63)) {
-              const int r = i >> 6;
-              const float pr = r ? prio[1] : prio[0], po = r ? post[1] : post[0];
-              const float vv = (float)((double)(pr * po) / (1.0 + (double)pr));
-              const float g = (float)(1.0 / (double)po * (double)sqrtf((float)(0.7212 * (double)vv + (double)(vv * vv))));
-              Gst[i] = g;
-              Hk[i] = po * g * g;
+              Gst[i] = (i >> 6) ? gnew[1] : gnew[0];
+              Hk[i] = (i >> 6) ? hknew[1] : hknew[0];
             }
             __syncthreads();
             float post_part = 0.0f;
@@ -464,8 +487,10 @@ __global__ __launch_bounds__(64) void nrspec_kernel(const NrArgs a) {
     __syncthreads();
   }
   // ---- the record back
-  for (int i = lane; i < 3 * 128; i += 64) st[kNrX + i] = (&Xs[0][0])[i];
-  for (int i = lane; i < 15 * 128; i += 64) st[kNrE + i] = (&Es[0][0])[i];
+  if (KIND == 1) {  // (the spectral function keeps NR_X[.][0] only within a frame and never touches NR_E)
+    for (int i = lane; i < 3 * 128; i += 64) st[kNrX + i] = (&Xs[0][0])[i];
+    for (int i = lane; i < 15 * 128; i += 64) st[kNrE + i] = (&Es[0][0])[i];
+  }
   for (int i = lane; i < 128; i += 64) {
     st[kNrGts1 + i] = Gts1[i];
     st[kNrGts0 + i] = Gts0[i];

@@ -525,7 +525,6 @@ int process_device_impl(t41rx_ctx *ctx, const float *dI, const float *dQ, float 
   if (!g.ok) return fail(T41RX_ERR_HIP, "hipSetDevice failed");
   const int seg = ctx->params.fft_length / 512;
   const bool nr_on = ctx->params.nrOptionSelect != 0 || ctx->params.ANR_notchOn != 0;  // (fft_length 512: params_valid)
-  if (nr_on && q15) return fail(T41RX_ERR_UNSUPPORTED, "noise reduction / notch are built for the f32 entry points");
   if (nr_on) {
     const int rc = ensure_nr(ctx);
     if (rc != T41RX_OK) return rc;

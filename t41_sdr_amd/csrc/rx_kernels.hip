@@ -2104,7 +2104,7 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC)>::kWaves * 64), 4) void 
                                                             : 4 * lane + 256 * u)) = make_float4(aud[0], aud[1], aud[2], aud[3]);
       continue;
     }
-    if (DEBUG && PART == 0 && a.aud_out) {
+    if ((DEBUG || WQ15) && PART == 0 && a.aud_out) {
       // noise reduction / notch on (Process.cpp:841-866): those stages sit between the demodulator and the
       // interpolators and run in kernels of their own (nr_kernels.hip) on the whole call's audio; this kernel
       // hands over the 256 samples of the frame in time order and leaves the interpolator memories alone
@@ -3535,9 +3535,12 @@ static hipError_t launch_long(const RxArgs &a, int mode, hipStream_t s) {
 hipError_t launch_back512(const RxArgs &a, hipStream_t s) {
   // the long-FFT pipeline's segment-parallel back kernel with one segment per frame: it takes its interpolator
   // memories from the channel's record and leaves the call's last ones there
-  if (a.seg != 1 || !a.aud24 || a.q15) return hipErrorInvalidValue;
+  if (a.seg != 1 || !a.aud24) return hipErrorInvalidValue;
   const int grid_par = (int)(((size_t)a.nchan * (size_t)((a.nframes + a.seg_run - 1) / a.seg_run) + 3) / 4);
-  hipLaunchKernelGGL((rx512_kernel<kModeSsb, false, 2, false, false, false, true>), dim3(grid_par), dim3(256), 0, s, a);
+  if (a.q15)  // arm_float_to_q15 behind the volume (Process.cpp:936)
+    hipLaunchKernelGGL((rx512_kernel<kModeSsb, false, 2, false, false, true, true>), dim3(grid_par), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((rx512_kernel<kModeSsb, false, 2, false, false, false, true>), dim3(grid_par), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 

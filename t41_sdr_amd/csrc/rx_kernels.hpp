@@ -74,7 +74,7 @@ struct RxArgs {
 constexpr int tab_long_entries(int R) { return (R - 1) * 512 + R * 512; }
 
 hipError_t launch_rx(const RxArgs &a, int fft_length, int mode, hipStream_t s);
-// FFT_LENGTH 512, behind launch_rx() with aud_out set: interpolators, volume and stores from a.aud24 (f32 samples out)
+// FFT_LENGTH 512, behind launch_rx() with aud_out set: interpolators, volume and stores from a.aud24 (f32 or q15 samples out)
 hipError_t launch_back512(const RxArgs &a, hipStream_t s);
 
 // display FFT (CalcZoom1Magn / ZoomFFTExe, FFT.cpp:67-251) on the dbg_pre tap of the frames just processed

@@ -325,13 +325,30 @@ def test_gpu_nr_split_reset_and_refusals(built):
         parts = [rx.ProcessIQData(dI[:, a * L:b * L].contiguous(), dQ[:, a * L:b * L].contiguous()).cpu().numpy()
                  for a, b in ((0, 1), (1, 6), (6, 12))]
         assert np.array_equal(np.concatenate(parts, axis=1), whole)
-    # q15 entry points, long FFT lengths, a pass band the spectral function's smoothing runs out of
-    rx = T.RxChain(2, T.default_params(ANR_notchOn=1))
-    z = torch.zeros(2, L, dtype=torch.int16, device="cuda")
-    with pytest.raises(T.T41RxError) as e:
-        rx.ProcessIQData_q15(z, z)
-    assert e.value.status == lib.ERR_UNSUPPORTED
+    # long FFT lengths, a pass band the spectral function's smoothing runs out of
     for bad in (dict(fft_length=1024, ANR_notchOn=1), dict(nrOptionSelect=2, FLoCut=400, FHiCut=600), dict(nrOptionSelect=4)):
         with pytest.raises(T.T41RxError) as e:
             T.RxChain(2, T.default_params(**bad))
         assert e.value.status == lib.ERR_ARG
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(ANR_notchOn=1), dict(nrOptionSelect=1), dict(nrOptionSelect=2, AGCMode=1)], ids=["notch", "kim", "spectral-agc"])
+def test_gpu_nr_q15(built, kw):
+    """the stages on the firmware's own sample format (Process.cpp:107-108, 936): bit for bit the f32 entry point on the
+    converted samples, then arm_float_to_q15"""
+    import torch
+    import t41_sdr_amd as T
+    nch, nfr = 5, 14
+    kw = dict(kw, audioVolume=70)
+    nco = siggen.nco_grid(nch, seed=9)
+    I, Q = siggen.make_iq(nch, nfr * L, nco, mode=0, seed=90)
+    qI = np.clip(np.round(I * 32768.0), -32768, 32767).astype(np.int16)
+    qQ = np.clip(np.round(Q * 32768.0), -32768, 32767).astype(np.int16)
+    rx = T.RxChain(nch, T.default_params(**kw), NCOFreq=nco)
+    got = rx.ProcessIQData_q15(torch.from_numpy(qQ).cuda(), torch.from_numpy(qI).cuda()).cpu().numpy()
+    rx.reset()
+    f = rx.ProcessIQData(torch.from_numpy(qI.astype(np.float32) / np.float32(32768)).cuda(),
+                         torch.from_numpy(qQ.astype(np.float32) / np.float32(32768)).cuda()).cpu().numpy()
+    want = np.clip(np.trunc(f.astype(np.float64) * 32768.0), -32768, 32767).astype(np.int16)
+    assert np.array_equal(got, want) and np.abs(got).max() > 200

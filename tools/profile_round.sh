@@ -5,16 +5,18 @@
 # copies the summaries into profiles/ and rewrites profiles/hbm_traffic.json.
 # usage: tools/profile_round.sh TAG [workload ...]
 TAG=$1; shift
-WL=${@:-ssb nfm nfm_atan am sam ssb_agc ssb_q15 fft4096}
+WL=${@:-ssb nfm nfm_atan am sam ssb_agc ssb_q15 fft4096 ssb_notch ssb_kim ssb_spectral}
 export TMPDIR=/tmp
-OUT=$GRAFT_REPO_ROOT/gpurun_out/profile_$TAG
-mkdir -p $OUT
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT="$ROOT/gpurun_out/profile_$TAG"
+mkdir -p "$OUT"
+export T41RX_BENCH_NOCHECK=1   # (the parity replay is bench.py's own business; here only the timed launches' kernels count)
 cd /tmp
 for W in $WL; do
   echo "== $W"
-  timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$W/trace -o t -- python3 $GRAFT_REPO_ROOT/bench.py --workload $W --steps 30 --warmup 5 --no-cpu-baseline > $OUT/$W.trace.log 2>&1 || echo "trace $W failed"
+  timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$W/trace -o t -- python3 "$ROOT/bench.py" --no-other-workloads --workload $W --steps 30 --warmup 5 --no-cpu-baseline > $OUT/$W.trace.log 2>&1 || echo "trace $W failed"
   for C in FETCH_SIZE WRITE_SIZE; do
-    timeout -k 10 240 rocprofv3 --pmc $C --output-format csv -d $OUT/$W/$C -o p -- python3 $GRAFT_REPO_ROOT/bench.py --workload $W --steps 6 --warmup 2 --no-cpu-baseline > $OUT/$W.$C.log 2>&1 || echo "pmc $C $W failed"
+    timeout -k 10 240 rocprofv3 --pmc $C --output-format csv -d $OUT/$W/$C -o p -- python3 "$ROOT/bench.py" --no-other-workloads --workload $W --steps 6 --warmup 2 --no-cpu-baseline > $OUT/$W.$C.log 2>&1 || echo "pmc $C $W failed"
   done
   tail -1 $OUT/$W.trace.log | cut -c1-200
 done
@@ -27,7 +29,7 @@ PASSES=(
 i=0
 for CNT in "${PASSES[@]}"; do
   i=$((i+1))
-  timeout -k 10 240 rocprofv3 --pmc $CNT --output-format csv -d $OUT/ssb/sq$i -o p -- python3 $GRAFT_REPO_ROOT/bench.py --workload ssb --steps 6 --warmup 2 --no-cpu-baseline > $OUT/ssb.sq$i.log 2>&1 || echo "sq pass $i failed"
+  timeout -k 10 240 rocprofv3 --pmc $CNT --output-format csv -d $OUT/ssb/sq$i -o p -- python3 "$ROOT/bench.py" --no-other-workloads --workload ssb --steps 6 --warmup 2 --no-cpu-baseline > $OUT/ssb.sq$i.log 2>&1 || echo "sq pass $i failed"
 done
 # keep the merge small: per-dispatch traces are not needed, and of the counter CSVs only our kernels' rows
 find $OUT -name "*kernel_trace.csv" -delete

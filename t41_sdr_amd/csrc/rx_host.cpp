@@ -43,6 +43,7 @@ struct t41rx_ctx {
   // FFT_LENGTH 4096 pipeline: constant table + scratch between its three kernels
   float2 *d_tab4k = nullptr;
   float *d_mid = nullptr, *d_aud24 = nullptr;
+  float *d_agc_pipe = nullptr;  // AGC on, FFT_LENGTH 512: the pipelined kernel's slots (RxArgs::agc_pipe), allocated on first use
   int scratch_frames = 0;
   int nco_sel = 0;               // long FFT: which NcoState copy is current (flips with every process call)
   // noise reduction / notch (Process.cpp:841-866): state of Xanr() and of the two spectral functions, window tables;
@@ -287,6 +288,15 @@ void free_ctx(t41rx_ctx *ctx) {
   (void)hipFree(ctx->d_tab4k);
   (void)hipFree(ctx->d_mid);
   (void)hipFree(ctx->d_aud24);
+  if (ctx->d_agc_pipe && std::getenv("T41RX_PIPE_STAT")) {  // diagnostic build's counters (rx_kernels.hip: PIPE_STAT_*)
+    unsigned long long c[16] = {};
+    std::vector<unsigned long long> all((size_t)ctx->nchan * 16);
+    (void)hipMemcpy(all.data(), ctx->d_agc_pipe + (size_t)ctx->nchan * 3 * 1024, all.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    for (size_t i = 0; i < all.size(); ++i) c[i & 15] += all[i];
+    std::fprintf(stderr, "pipe_stat chain_cycles %llu chains %llu slow_blocks %llu back_wait %llu duty_wait %llu blocks %llu chain_stage %llu chain_steps %llu front %llu prep %llu back %llu wave_iterations %llu\n",
+                 c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8], c[9], c[10], c[11]);
+  }
+  (void)hipFree(ctx->d_agc_pipe);
   (void)hipFree(ctx->d_in_i);
   (void)hipFree(ctx->d_in_q);
   (void)hipFree(ctx->d_out);
@@ -583,6 +593,14 @@ int process_device_impl(t41rx_ctx *ctx, const float *dI, const float *dQ, float 
     a.seg_run = (int)(run < 1 ? 1 : (run > 8 ? 8 : (run > segs ? segs : run)));
   }
   a.agc = ctx->params.AGCMode != 0 ? 1 : 0;
+  if (a.agc && seg == 1 && ctx->params.mode != T41RX_DEMOD_SAM && n_frames >= 4) {
+    if (!ctx->d_agc_pipe) {  // (+ 8 counters per wave of the -DT41RX_PIPE_STAT diagnostic build)
+      const size_t bytes = (size_t)ctx->nchan * 3 * 1024 * sizeof(float) + ((size_t)ctx->nchan + 16) * 16 * sizeof(unsigned long long);
+      HIP_TRY(hipMalloc((void **)&ctx->d_agc_pipe, bytes));
+      HIP_TRY(hipMemset(ctx->d_agc_pipe, 0, bytes));
+    }
+    a.agc_pipe = ctx->d_agc_pipe;
+  }
   if (a.agc && (int)blob_view(ctx->blob.data()).agc[kAgcAttackBuffsize] != kAgcDelay)
     return fail(T41RX_ERR_STATE, "coefficient blob carries an AGC look-ahead the kernel is not built for");
   if ((ctx->dbg_nco || ctx->dbg_dec || ctx->dbg_demod) && n_frames > ctx->tap_frames)

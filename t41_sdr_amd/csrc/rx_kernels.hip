@@ -922,6 +922,279 @@ __device__ __forceinline__ void agc_apply(const cf (&v)[8], float4 agst, float *
   STAMP(23);  // AGC: gain from volts, scaling, record store
 }
 
+// ------------------------------------------------------------------------------------------
+// AGC on, pipelined (rx512_kernel<..., PIPE = true>): the serial chain of frame g runs WHILE the
+// other waves of the workgroup work on the front end of frame g + 1 / g + 2 and the back end of
+// frame g - 1, instead of between two workgroup barriers.
+//   * Geometry of the AGC-off kernel: one resident 16-wave workgroup per CU, one channel per wave,
+//     filter memories on chip for the whole launch.
+//   * The chain of frame g is run by ONE wave (g mod the workgroup's channel count: the duty
+//     rotates) for all the workgroup's channels, one lane per channel, 16 channels' worth of
+//     instruction issue for the price of one.  Its inputs (look-ahead maxima, |popped sample|) and
+//     outputs (volts) and the popped samples the gain is applied to travel through a per-channel
+//     ring of three slots in global memory (RxArgs::agc_pipe; the slices have no LDS left, and
+//     the AGC's delay line rides in four registers): a wave's program per iteration f is
+//         front end + AGC preparation of frame f     -> slot f mod 3, ready[f mod 3] += 1
+//         (duty wave of frame f - 1) chain of f - 1  -> waits for ready == channels and done == f - 1
+//         gain + demodulator + back end of f - 2     -> waits for done > f - 2 (its loads are
+//                                                       requested ahead of the preparation when the
+//                                                       chain is done by then, which is the rule)
+//     The back end trails by TWO frames: the wave that ran a chain is one chain (~60 k cycles)
+//     behind the others from then on, and the next chain needs ITS channel's inputs too -- with a
+//     single frame of slack that lag would sit on the chain's critical path every frame.
+//   * Flags: four words of LDS behind the FFT twiddles; waits are bounded spins (a logic error
+//     then shows as wrong samples in the parity tests, not as a hung GPU).  Release / acquire at
+//     workgroup scope: the waves of a workgroup share the CU's vector memory path and L1, which
+//     keeps their global accesses in order, so the fences cost an LDS wait and no vmcnt(0).
+// Every value is computed by the same instructions as in agc_apply / agc_chain: bit-identical
+// (tools/agc_pipe_probe.py, tests/test_gpu_parity.py::test_agc_pipelined_equals_barrier_form).
+// Measured (MI355X, 4096 channels x 32 frames, tools/agc_pipe_round.sh, -DT41RX_PIPE_STAT counters):
+// 33 us per frame against 39-40 for the barrier form.  A chain takes 57-64 k cycles (175-200 per
+// step + staging), a wave's front end 38 k, preparation 9 k, back end 10 k wall cycles per frame;
+// the slots cost 8 KiB of fabric traffic per channel-frame on top of the 24 KiB of samples (they
+// miss L2: the 4096-channel working set is 5 MiB per XCD), but removing half of it in a timing
+// experiment bought 5 %: what binds is instruction issue -- the SIMD that hosts the chain carries
+// it (~33 k issue cycles per frame) on top of its four waves' own work while the other three idle
+// part of the time -- and behind that the chain's own latency (~25 us per frame).
+// ------------------------------------------------------------------------------------------
+constexpr int kPipeSlots = 3, kPipeSlotFloats = 1024;  // ring_max -> volts [256] | |popped| [256] | popped re [256] | popped im [256] (AM only)
+constexpr int kPipeFlags = 1008;                        // float index in the table area: ready[3], done
+constexpr int kPipeSpinCap = 1 << 20;
+
+// -DT41RX_PIPE_STAT (diagnostic build, tools/build_variant.sh pstat -DT41RX_PIPE_STAT; T41RX_PIPE_STAT=1 prints them when
+// the context is destroyed): 16 cycle counters per wave behind the slots -- [0] chain [1] chains [2] slow blocks [3] waiting
+// for a chain's results [4] duty wave waiting before its chain [5] blocks [6] chain: staging [7] chain: the steps
+// [8] front end [9] AGC preparation [10] back end [11] iterations
+#ifdef T41RX_PIPE_STAT
+#define PIPE_STAT_T0() const unsigned long long pipe_t0 = __builtin_readcyclecounter()
+#define PIPE_STAT_ADD(k) do { if (lane == 0) pipe_stat[k] += __builtin_readcyclecounter() - pipe_t0; } while (0)  // (a wave's own eight counters)
+#define PIPE_STAT_INC(k, n) do { if (lane == 0) pipe_stat[k] += (unsigned long long)(n); } while (0)
+#else
+#define PIPE_STAT_T0() do {} while (0)
+#define PIPE_STAT_ADD(k) do {} while (0)
+#define PIPE_STAT_INC(k, n) do {} while (0)
+#endif
+__device__ __forceinline__ unsigned pipe_flag_read(const unsigned *p) {
+  return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+}
+__device__ __forceinline__ void pipe_wait_ge(const unsigned *p, unsigned target) {
+  for (int it = 0; it < kPipeSpinCap; ++it) {
+    if (pipe_flag_read(p) >= target) break;
+    __builtin_amdgcn_s_sleep(2);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// first half of agc_apply: magnitudes, look-ahead maxima; what the chain and the gain need -> slot
+template <typename AL, bool NEED_IM>
+__device__ __forceinline__ float4 agc_prep_pipe(const cf (&v)[8], float4 agst, float *lds, float *slot, CoefPtr cf0, int lane) {
+  constexpr int kAgZ = AL::Z, kAgA = AL::A, kAgG = AL::G;
+  wave_sync();
+  if (lane < 50) *reinterpret_cast<float4 *>(lds + kAgZ + 4 * lane) = agst;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    *reinterpret_cast<cf *>(lds + kAgZ + 2 * (100 + lane + 64 * j)) = v[4 + j];
+    lds[kAgA + 100 + lane + 64 * j] = agc_mag(v[4 + j]);
+  }
+  if (lane < 50) *reinterpret_cast<float2 *>(lds + kAgA + 2 * lane) = make_float2(agc_mag(cf{agst.x, agst.y}), agc_mag(cf{agst.z, agst.w}));
+  wave_sync();
+  {
+    float4 t = lds4(lds + kAgA + 4 * lane);
+    lds[kAgG + lane] = fmaxf(fmaxf(t.x, t.y), fmaxf(t.z, t.w));
+    if (lane < 25) {
+      t = lds4(lds + kAgA + 256 + 4 * lane);
+      lds[kAgG + 64 + lane] = fmaxf(fmaxf(t.x, t.y), fmaxf(t.z, t.w));
+    }
+  }
+  wave_sync();
+  {
+    const float4 nv = lds4(lds + kAgA + 100 + 4 * lane);
+    const float4 g1 = lds4(lds + kAgA + 4 + 4 * lane);
+    const float ao0 = lds[kAgA + 3 + 4 * lane];
+    float C = lds[kAgG + lane + 2];
+#pragma unroll
+    for (int q = 3; q <= 24; ++q) C = fmaxf(C, lds[kAgG + lane + q]);
+    const float s3 = g1.w, s2 = fmaxf(g1.z, s3), s1 = fmaxf(g1.y, s2), s0 = fmaxf(g1.x, s1);
+    const float p0 = nv.x, p1 = fmaxf(p0, nv.y), p2 = fmaxf(p1, nv.z), p3 = fmaxf(p2, nv.w);
+    *reinterpret_cast<float4 *>(slot + 4 * lane) =
+        make_float4(fmaxf(fmaxf(s0, C), p0), fmaxf(fmaxf(s1, C), p1), fmaxf(fmaxf(s2, C), p2), fmaxf(fmaxf(s3, C), p3));
+    *reinterpret_cast<float4 *>(slot + 256 + 4 * lane) = make_float4(ao0, g1.x, g1.y, g1.z);
+    cf z[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) z[k] = *reinterpret_cast<const cf *>(lds + kAgZ + 2 * (3 + 4 * lane + k));
+    *reinterpret_cast<float4 *>(slot + 512 + 4 * lane) = make_float4(z[0].x, z[1].x, z[2].x, z[3].x);
+    if (NEED_IM) *reinterpret_cast<float4 *>(slot + 768 + 4 * lane) = make_float4(z[0].y, z[1].y, z[2].y, z[3].y);
+  }
+  // the delay line for the next frame: the newest 100 inputs, kept in registers (lanes 0..49; the state words are the chain's)
+  const float4 rec = lds4(lds + kAgZ + 512 + 4 * (lane < 50 ? lane : 0));
+  wave_sync();
+  return rec;
+}
+
+// agc_chain for one channel per lane.  The operands wait in the channels' slots, i.e. in L2 / MALL / HBM behind the
+// streaming traffic of fifteen other waves: several microseconds away.  The duty wave therefore moves them through
+// its own LDS scratch (free between its AGC preparation and its back end) in chunks of 16 steps for all the
+// channels at once -- lane (channel, quarter) loads one float4 of ring_max and one of |popped| per chunk --, requested
+// kPipeAhead chunks (64 steps) ahead; the first ones before the wait for the previous frame's chain.
+//   grp   : slot (frame g) of the workgroup's first channel; channel c's is kPipeSlots * kPipeSlotFloats * c further
+//   stw0  : the eight state words of the workgroup's first channel, channel c's stride floats further
+//   stage : kPipeStageFloats of LDS
+constexpr int kPipeChunk = 16, kPipeChStride = 52;  // per channel in the stage: ring_max -> volts [16] | (b x) pairs [32] | 4 pad
+constexpr int kPipeStageFloats = 16 * kPipeChStride;
+#ifndef T41RX_PIPE_AHEAD
+#define T41RX_PIPE_AHEAD 4
+#endif
+__device__ __forceinline__ void agc_chain_pipe(float *grp, float *stw0, size_t stride, float *stage, const unsigned *done, unsigned g,
+                                               int nvalid, CoefPtr cf0, int lane, unsigned long long *pipe_stat) {
+  const CoefPtr c = fresh_coef(cf0);
+  AgcConsts gc;
+  gc.attack_mult = c->agc[kAgcAttackMult];
+  gc.decay_mult = c->agc[kAgcDecayMult];
+  gc.fast_decay_mult = c->agc[kAgcFastDecayMult];
+  gc.hang_decay_mult = c->agc[kAgcHangDecayMult];
+  gc.onemfast_backmult = c->agc[kAgcOnemFastBackmult];
+  gc.onemhang_backmult = c->agc[kAgcOnemHangBackmult];
+  gc.min_volts = c->agc[kAgcMinVolts];
+  gc.hang_level = c->agc[kAgcHangLevel];
+  gc.pop_ratio = c->agc[kAgcPopRatio];
+  gc.hang_count = (int)c->agc[kAgcHangCount];
+  float fast_backmult = c->agc[kAgcFastBackmult], hang_backmult = c->agc[kAgcHangBackmult];
+  asm volatile("" : "+v"(fast_backmult), "+v"(hang_backmult));
+  const int ch = (nvalid == 16) ? (lane & 15) : (lane & 15) % nvalid;  // this lane's channel, as a loader and as a chain
+  const int q = lane >> 4;                                              // the float4 of a chunk it moves
+  float *gsrc = grp + (size_t)ch * (kPipeSlots * kPipeSlotFloats) + 4 * q;
+  float *sw = stage + ch * kPipeChStride;
+  constexpr int AH = T41RX_PIPE_AHEAD;
+  float4 pr[AH], pa[AH];
+#pragma unroll
+  for (int u = 0; u < AH; ++u) {
+    pr[u] = *reinterpret_cast<const float4 *>(gsrc + kPipeChunk * u);
+    pa[u] = *reinterpret_cast<const float4 *>(gsrc + 256 + kPipeChunk * u);
+  }
+  {
+    PIPE_STAT_T0();
+    pipe_wait_ge(done, g);  // the previous frame's chain has left the state words
+    PIPE_STAT_ADD(4);
+  }
+  PIPE_STAT_T0();
+  float *stw = stw0 + (size_t)ch * stride;
+  const float4 sf = *reinterpret_cast<const float4 *>(stw);
+  const int4 si = *reinterpret_cast<const int4 *>(stw + 4);
+  AgcState st{sf.x, sf.y, sf.z, sf.w, si.x, si.y, si.z};
+  AgcLane d = agc_lane_of(st, gc);
+#ifdef T41RX_PIPE_STAT
+  unsigned long long acc_stage = 0, acc_comp = 0, acc_slow = 0;
+#endif
+  // (rolled loops: one copy of the four-step block -- ~1300 instructions -- instead of sixteen; the register ring
+  // of requested chunks rotates by moves)
+#pragma nounroll
+  for (int k = 0; k < 256 / kPipeChunk; ++k) {
+    {
+      const float4 r4c = pr[0], a4c = pa[0];
+#pragma unroll
+      for (int u = 0; u + 1 < AH; ++u) {
+        pr[u] = pr[u + 1];
+        pa[u] = pa[u + 1];
+      }
+      if (k + AH < 256 / kPipeChunk) {
+        pr[AH - 1] = *reinterpret_cast<const float4 *>(gsrc + kPipeChunk * (k + AH));
+        pa[AH - 1] = *reinterpret_cast<const float4 *>(gsrc + 256 + kPipeChunk * (k + AH));
+      }
+      wave_sync();
+#ifdef T41RX_PIPE_STAT
+      const unsigned long long ts0 = __builtin_readcyclecounter();
+#endif
+      *reinterpret_cast<float4 *>(sw + 4 * q) = r4c;
+      {
+#pragma clang fp contract(off)
+        *reinterpret_cast<float4 *>(sw + 16 + 8 * q) = make_float4(fast_backmult * a4c.x, hang_backmult * a4c.x, fast_backmult * a4c.y, hang_backmult * a4c.y);
+        *reinterpret_cast<float4 *>(sw + 16 + 8 * q + 4) = make_float4(fast_backmult * a4c.z, hang_backmult * a4c.z, fast_backmult * a4c.w, hang_backmult * a4c.w);
+      }
+      wave_sync();
+#ifdef T41RX_PIPE_STAT
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      acc_stage += __builtin_readcyclecounter() - ts0;  // staging the chunk's operands
+#endif
+    }
+#ifdef T41RX_PIPE_STAT
+    const unsigned long long ts1 = __builtin_readcyclecounter();
+#endif
+    float4 nr4 = lds4(sw), npa = lds4(sw + 16), npb = lds4(sw + 20);
+#pragma nounroll
+    for (int b = 0; b < 4; ++b) {
+      const float4 r4 = nr4, pa4 = npa, pb4 = npb;
+      if (b < 3) {
+        nr4 = lds4(sw + 4 * b + 4);
+        npa = lds4(sw + 16 + 8 * b + 8);
+        npb = lds4(sw + 16 + 8 * b + 12);
+      }
+      const float rm[4] = {r4.x, r4.y, r4.z, r4.w};
+      const float pf[4] = {pa4.x, pa4.z, pb4.x, pb4.z}, ph[4] = {pa4.y, pa4.w, pb4.y, pb4.w};
+      float vo[4];
+      AgcState t = st;
+      AgcLane dt = d;
+      lanemask ok;
+      if ((d.is3 & ~d.in0) != 0)
+        ok = agc_fast_block<true>(t, dt, gc, rm, pf, ph, vo);
+      else
+        ok = agc_fast_block<false>(t, dt, gc, rm, pf, ph, vo);
+      if (~ok != 0) {
+#ifdef T41RX_PIPE_STAT
+        acc_slow += 1;
+#endif
+        if (((~ok >> lane) & 1ull) != 0) {
+          t = st;
+          agc_slow_block(t, gc, rm, pf, ph, vo);
+        }
+        dt = agc_lane_of(t, gc);
+      }
+      st = t;
+      d = dt;
+      *reinterpret_cast<float4 *>(sw + 4 * b) = make_float4(vo[0], vo[1], vo[2], vo[3]);  // (every lane of a channel writes the same)
+    }
+    wave_sync();
+#ifdef T41RX_PIPE_STAT
+    acc_comp += __builtin_readcyclecounter() - ts1;  // the chunk's 16 steps
+#endif
+    *reinterpret_cast<float4 *>(gsrc + kPipeChunk * k) = lds4(sw + 4 * q);  // volts in ring_max's place
+  }
+  if (lane < nvalid) {
+    *reinterpret_cast<float4 *>(stw) = make_float4(st.fast_backaverage, st.hang_backaverage, st.volts, st.save_volts);
+    *reinterpret_cast<int4 *>(stw + 4) = make_int4(st.state, st.decay_type, st.hang_counter, 0);
+  }
+  PIPE_STAT_ADD(0);
+  PIPE_STAT_INC(1, 1);
+  PIPE_STAT_INC(5, 64);
+#ifdef T41RX_PIPE_STAT
+  PIPE_STAT_INC(2, acc_slow);
+  PIPE_STAT_INC(6, acc_stage);
+  PIPE_STAT_INC(7, acc_comp);
+#endif
+}
+
+// last part of agc_apply: og[k] = popped sample 4 lane + k times the gain from volts
+struct AgcGainIn { float4 vv, zr, zi; };  // requested ahead of the AGC preparation of the front end's frame, which hides the round trip
+template <bool NEED_IM>
+__device__ __forceinline__ AgcGainIn agc_gain_request(const float *slot, int lane) {
+  AgcGainIn r;
+  r.vv = *reinterpret_cast<const float4 *>(slot + 4 * lane);
+  r.zr = *reinterpret_cast<const float4 *>(slot + 512 + 4 * lane);
+  r.zi = make_float4(0, 0, 0, 0);
+  if (NEED_IM) r.zi = *reinterpret_cast<const float4 *>(slot + 768 + 4 * lane);
+  return r;
+}
+__device__ __forceinline__ void agc_gain_pipe(const AgcGainIn &in, CoefPtr cf0, cf (&og)[4]) {
+  const CoefPtr c = fresh_coef(cf0);
+  const float inv_max_input = c->agc[kAgcInvMaxInput], out_target = c->agc[kAgcOutTarget], slope_constant = c->agc[kAgcSlopeConstant];
+  const float4 vv = in.vv, zr = in.zr, zi = in.zi;
+  const float vk[4] = {vv.x, vv.y, vv.z, vv.w}, re[4] = {zr.x, zr.y, zr.z, zr.w}, im[4] = {zi.x, zi.y, zi.z, zi.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float mult = agc_mult(vk[k], inv_max_input, out_target, slope_constant);
+    og[k] = cf{re[k] * mult, im[k] * mult};
+  }
+}
+
 constexpr int kModeSsb = 0, kModeAm = 1, kModeNfm = 2, kModeSam = 3;  // kernel template MODE
 // the 4-wave geometry (Geo's second parameter): AGC on, and the synchronous detector, whose PLL is a serial
 // chain run by one wave per workgroup like the AGC's
@@ -999,10 +1272,11 @@ static_assert(!Geo<0>::kResident || (Geo<0>::kH1 + 24 <= Geo<0>::kSlice && Geo<0
 // start-up transient); back end = the previous segment's last 28 audio samples.  The channel's
 // state is written by the wave that READ it (the one that starts the call), from the call's last
 // samples in the same way: a wave of a later run may execute before that one has started.
-template <int MODE, bool DEBUG, int PART, bool PLAIN, bool AGC = false, bool WQ15 = false, bool SEGPAR = false>
-__global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC)>::kWaves * 64), 4) void rx512_kernel(const RxArgs a) {
+template <int MODE, bool DEBUG, int PART, bool PLAIN, bool AGC = false, bool WQ15 = false, bool SEGPAR = false, bool PIPE = false>
+__global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64), 4) void rx512_kernel(const RxArgs a) {
   static_assert(!SEGPAR || (PART == 1 && MODE != kModeNfm) || (PART == 2 && MODE == kModeSsb && !AGC), "SEGPAR variants");
-  typedef Geo<PART, geo4(MODE, AGC)> G;
+  static_assert(!PIPE || (AGC && PART == 0 && MODE != kModeSam && !DEBUG && !SEGPAR && T41RX_RESIDENT), "PIPE: the pipelined AGC variant (see agc_prep_pipe)");
+  typedef Geo<PART, geo4(MODE, AGC) && !PIPE> G;
   constexpr bool KEEP = G::kResident;  // streaming state stays on chip across the frames of a launch
   constexpr int NW = G::kWaves;
   constexpr int kX = G::kX, kY1 = G::kY1, kScr = G::kScr, kI1 = G::kI1;
@@ -1040,6 +1314,8 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC)>::kWaves * 64), 4) void 
       else if (threadIdx.x >= 256 && threadIdx.x < 256 + 56)
         reinterpret_cast<float2 *>(smem)[G::kTw2 + threadIdx.x - 256] =
             a.tab[kTabTw2 + 64 * ((threadIdx.x - 256) >> 3) + ((threadIdx.x - 256) & 7)];
+      else if (PIPE && threadIdx.x >= 320 && threadIdx.x < 328)
+        reinterpret_cast<unsigned *>(smem)[kPipeFlags + threadIdx.x - 320] = 0u;  // ready[3], done (see agc_prep_pipe)
     } else if (MODE == kModeSam) {
       // the mask is read from the L2-resident table (as the resident kernels do); its place holds
       // arm_sin_f32's 513-entry table for the PLL's per-lane look-ups
@@ -1102,6 +1378,7 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC)>::kWaves * 64), 4) void 
   cf nfm_carry = splat(0.0f);  // PART 1, NFM: the previous segment's last complex sample
   float4 hist1c = make_float4(0, 0, 0, 0);
   float hist2c = 0.0f, audn[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  float4 agrec = make_float4(0, 0, 0, 0);  // PIPE: the AGC's delay line (its last 100 inputs), lanes 0..49, across the frames of a launch
 #ifdef T41RX_STAMP
   unsigned long long stamp_acc = 0, stamp_last;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
@@ -1148,15 +1425,22 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC)>::kWaves * 64), 4) void 
       xp[2 * u + 1] = up[u].y;
     }
   };
-  for (int f = seg0; f < seg1; ++f) {
+  // PIPE: the back end trails the front end by two frames (see agc_prep_pipe): two more iterations
+  constexpr int kSkew = PIPE ? 2 : 0;
+  for (int f = seg0; f < seg1 + kSkew; ++f) {
+#ifdef T41RX_PIPE_STAT
+    unsigned long long ps_t = __builtin_readcyclecounter();  // [8] front end [9] AGC preparation [10] back end [11] iterations
+#endif
     if (AGC) PRIO(2); else PRIO(3);  // (AGC on: 3 is the serial chain's, see agc_apply)
     FRESH_LANE();
     const bool first_iter = (f == seg0);
     const size_t fbase = ((size_t)(T41RX_ABLATE == 9 ? (ch & 15) : ch) * a.nframes + f) * L;
+    const int fb = PIPE ? (f >= kSkew ? f - kSkew : 0) : f;  // the frame the back end works on
+    const size_t fbase_o = ((size_t)(T41RX_ABLATE == 9 ? (ch & 15) : ch) * a.nframes + fb) * L;
     // (WQ15: two samples per float slot, so sample offsets halve)
     const float *__restrict__ gI = a.I + (WQ15 ? fbase / 2 : fbase);
     const float *__restrict__ gQ = a.Q + (WQ15 ? fbase / 2 : fbase);
-    float *__restrict__ gO = a.out + (WQ15 ? fbase / 2 : fbase);
+    float *__restrict__ gO = a.out + (WQ15 ? fbase_o / 2 : fbase_o);
 
     constexpr bool CONTIG = (MODE == kModeAm) || (AGC && MODE != kModeSam);  // aud[j] = sample 4 lane + j instead of lane + 64 j
     float aud[4];                            // 4 demodulated samples @24 kS/s
@@ -1205,7 +1489,7 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC)>::kWaves * 64), 4) void 
 #pragma unroll
         for (int j = 0; j < 4; ++j) audn[j] = au[D + lane + 64 * j];
       }
-    } else {
+    } else if (!PIPE || f < seg1) {
       // ---- first loads of the frame, issued in the order they are needed (vmcnt retires in
       // order): sub-block 0, the I tail for Q's DC-block start state, the delay lines, then
       // sub-block 1.  Input prefetch runs TWO sub-blocks ahead (two register sets, even / odd).
@@ -1677,7 +1961,11 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC)>::kWaves * 64), 4) void 
       } else {
         hist2 = hist2c;
       }
-      if (AGC && lane < 52) agst = *reinterpret_cast<const float4 *>(st + st_agc(512) + 4 * lane);
+      if (PIPE) {
+        if (first_iter && lane < 50) agrec = *reinterpret_cast<const float4 *>(st + st_agc(512) + 4 * lane);
+      } else if (AGC && lane < 52) {
+        agst = *reinterpret_cast<const float4 *>(st + st_agc(512) + 4 * lane);
+      }
       wave_sync();
 
       // ---- level adjust (Process.cpp:481-492): folded into the /2 decimator's taps by the host (DevCoef::dec2)
@@ -1928,7 +2216,69 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC)>::kWaves * 64), 4) void 
       // SSB/NFM: audio = Re
       const float fixed_gain = fresh_coef(cf0)->sc[kScFixedGain];
       cf og[4];
-      if (AGC) {
+      if (PIPE) {
+        const int left = a.nchan - NW * (int)blockIdx.x;
+        const int nvalid = left < NW ? left : NW;
+        unsigned *flags = reinterpret_cast<unsigned *>(smem) + kPipeFlags;
+        constexpr bool NEED_IM = (MODE == kModeAm);
+        unsigned long long *pipe_stat = reinterpret_cast<unsigned long long *>(a.agc_pipe + (size_t)a.nchan * kPipeSlots * kPipeSlotFloats) + (size_t)job * 16;
+        (void)pipe_stat;
+#ifdef T41RX_PIPE_STAT
+        if (f < seg1 && lane == 0) {
+          const unsigned long long now = __builtin_readcyclecounter();
+          pipe_stat[8] += now - ps_t;
+          pipe_stat[11] += 1;
+          ps_t = now;
+        }
+#endif
+        // the back end's frame: if its chain is done by now (the rule), volts and the popped samples are requested here,
+        // ahead of the front end's AGC preparation, which hides the round trip; if not, behind it -- waiting HERE would put
+        // the duty wave's preparation on the path from one chain to the next
+        AgcGainIn gin{};
+        const float *bslot = a.agc_pipe + ((size_t)ch * kPipeSlots + fb % kPipeSlots) * kPipeSlotFloats;
+        const bool early = f >= seg0 + kSkew && pipe_flag_read(flags + 3) >= (unsigned)(fb + 1);
+        if (early) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+          gin = agc_gain_request<NEED_IM>(bslot, lane);
+        }
+        if (f < seg1) {  // this frame's chain operands and popped samples -> the channel's slot
+          agrec = agc_prep_pipe<AgcLds<true>, NEED_IM>(v, agrec, lds, a.agc_pipe + ((size_t)ch * kPipeSlots + f % kPipeSlots) * kPipeSlotFloats, cf0, lane);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          if (lane == 0) __hip_atomic_fetch_add(flags + f % kPipeSlots, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef T41RX_PIPE_STAT
+          if (lane == 0) pipe_stat[9] += __builtin_readcyclecounter() - ps_t;
+#endif
+        }
+        const int g = f - 1;  // the frame whose chain is due
+        if (g >= seg0 && g < seg1 && g % nvalid == wv) {
+          {
+            PIPE_STAT_T0();
+            pipe_wait_ge(flags + g % kPipeSlots, (unsigned)nvalid);
+            PIPE_STAT_ADD(4);
+          }
+          if (lane == 0) __hip_atomic_store(flags + g % kPipeSlots, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          const size_t ch0 = (size_t)NW * blockIdx.x;
+          PRIO(3);  // the critical path of the whole workgroup, one dependent instruction at a time
+          static_assert(!PIPE || (NW == 16 && kScr + kPipeStageFloats <= G::kXF), "chain staging: 16 channels, inside the X scratch");
+          agc_chain_pipe(a.agc_pipe + (ch0 * kPipeSlots + g % kPipeSlots) * kPipeSlotFloats, a.state + ch0 * state_stride + st_agc(512) + kAgcHistFloats,
+                         state_stride, lds + kScr, flags + 3, (unsigned)g, nvalid, cf0, lane, pipe_stat);
+          PRIO(1);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          if (lane == 0) __hip_atomic_store(flags + 3, (unsigned)(g + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (f < seg0 + kSkew) continue;  // nothing to finish yet
+        if (!early) {
+          PIPE_STAT_T0();
+          pipe_wait_ge(flags + 3, (unsigned)(fb + 1));
+          PIPE_STAT_ADD(3);
+          gin = agc_gain_request<NEED_IM>(bslot, lane);
+        }
+#ifdef T41RX_PIPE_STAT
+        ps_t = __builtin_readcyclecounter();
+#endif
+        agc_gain_pipe(gin, cf0, og);
+        if (KEEP) hist2 = hist2c;
+      } else if (AGC) {
         const int left = a.nchan - NW * (int)blockIdx.x;
         agc_apply<AgcLds<KEEP>, NW, G::kSlice>(v, agst, lds, smem + G::kTab, st + st_agc(512 * seg), cf0, lane, wv,
                                                left < NW ? left : NW, og STAMP_ARGS);
@@ -2108,7 +2458,7 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC)>::kWaves * 64), 4) void 
       // noise reduction / notch on (Process.cpp:841-866): those stages sit between the demodulator and the
       // interpolators and run in kernels of their own (nr_kernels.hip) on the whole call's audio; this kernel
       // hands over the 256 samples of the frame in time order and leaves the interpolator memories alone
-      float *ao = a.aud_out + ((size_t)ch * a.nframes + f) * D;
+      float *ao = a.aud_out + ((size_t)ch * a.nframes + fb) * D;
       if (CONTIG) {
         *reinterpret_cast<float4 *>(ao + 4 * lane) = make_float4(aud[0], aud[1], aud[2], aud[3]);
       } else {
@@ -2298,6 +2648,10 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC)>::kWaves * 64), 4) void 
       }
     }
     STAMP(13);  // transposed reads + global stores
+#ifdef T41RX_PIPE_STAT
+    if (PIPE && lane == 0)
+      (reinterpret_cast<unsigned long long *>(a.agc_pipe + (size_t)a.nchan * kPipeSlots * kPipeSlotFloats) + (size_t)job * 16)[10] += __builtin_readcyclecounter() - ps_t;
+#endif
   }  // frames
 #ifdef T41RX_STAMP
   // stamps go behind the demod tap's data: dbg_demod must be [nchan*nframes*256 floats | nchan*64 uint64]
@@ -2310,6 +2664,7 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC)>::kWaves * 64), 4) void 
     reinterpret_cast<unsigned long long *>(a.dbg_demod + (size_t)a.nchan * a.nframes * D)[(size_t)ch * 64 + lane] = stamp_acc;
 #endif
 
+  if (PIPE && lane < 50) *reinterpret_cast<float4 *>(st + st_agc(512) + 4 * lane) = agrec;
   if (KEEP) {  // the channel's record goes back to HBM once per launch
     wave_sync();
     if (lane < 14) *reinterpret_cast<float4 *>(st + kStDec1 + 4 * lane) = lds4(lds + kX + 2 * xpad(2 * lane));
@@ -3411,6 +3766,26 @@ static hipError_t launch512(const RxArgs &a, hipStream_t s, bool debug) {
 #define T41RX_GO(DBG, PLN, AGCv, Q15v)                                                                   \
   hipLaunchKernelGGL((rx512_kernel<MODE, DBG, 0, PLN, AGCv, Q15v>),                                      \
                      dim3((a.nchan + Geo<0, AGCv>::kWaves - 1) / Geo<0, AGCv>::kWaves), dim3(Geo<0, AGCv>::kWaves * 64), 0, s, a)
+  // AGC on, calls of four frames or more without taps: the pipelined variant (agc_prep_pipe); shorter calls have
+  // nothing to overlap and take the barrier form, which computes the same values (T41RX_AGC_PIPE=0: experiments, tests)
+  static const bool pipe_env = [] {
+    const char *e = std::getenv("T41RX_AGC_PIPE");
+    return !e || std::atoi(e) != 0;
+  }();
+  if constexpr (MODE != kModeSam) {
+    if (a.agc && a.agc_pipe && !debug && a.nframes >= 4 && pipe_env) {
+#define T41RX_GOP(PLN, Q15v)                                                                             \
+  hipLaunchKernelGGL((rx512_kernel<MODE, false, 0, PLN, true, Q15v, false, true>), dim3((a.nchan + Geo<0>::kWaves - 1) / Geo<0>::kWaves), \
+                     dim3(Geo<0>::kWaves * 64), 0, s, a)
+      if (a.q15) {
+        if (a.plain) T41RX_GOP(true, true); else T41RX_GOP(false, true);
+      } else {
+        if (a.plain) T41RX_GOP(true, false); else T41RX_GOP(false, false);
+      }
+#undef T41RX_GOP
+      return hipGetLastError();
+    }
+  }
   if (a.q15) {  // the firmware's q15 sample format either side (no debug taps: refused by the host)
     if (a.agc) {
       if (a.plain)

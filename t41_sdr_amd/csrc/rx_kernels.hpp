@@ -66,6 +66,9 @@ struct RxArgs {
   // demodulator and leaves the frame's 256 audio samples @24 kS/s here, [nchan][nframes * 256] in time order;
   // nr_kernels.hip then runs Process.cpp:841-866 on them in place and launch_back512() interpolates (aud24 = this)
   float *aud_out;
+  // AGC on, pipelined kernel (rx_kernels.hip: agc_prep_pipe): per channel three slots of 1024 floats -- the serial
+  // chain's operands and results and the samples the gain is applied to, for the frames in flight (or null: barrier form)
+  float *agc_pipe;
 };
 
 // constant table of the N = 512 R point fast convolution (float2 units):

@@ -183,6 +183,31 @@ def test_parity_agc(T, agcmode, mode, nfr, segs):
     assert np.array_equal(got, split)
 
 
+@pytest.mark.parametrize("nch,mode,agcmode", [(5, 0, 1), (21, 2, 3), (37, 3, 4), (64, 0, 2)], ids=["5ch-usb", "21ch-am", "37ch-nfm", "64ch-usb"])
+def test_agc_pipelined_equals_barrier_form(T, nch, mode, agcmode):
+    """Calls of four frames or more run the pipelined AGC kernel (rx_kernels.hip: agc_prep_pipe -- the chain of one
+    frame on a rotating duty wave while the others work on the neighbouring frames), shorter ones the barrier form:
+    the same samples and the same checkpoint, bit for bit, on ragged batches (last workgroup 5 of 16 channels)"""
+    nfr = 14
+    nco = siggen.nco_grid(nch, seed=40 + nch)
+    if mode == 3:
+        I, Q = siggen.make_fm(nch, nfr * L, nco, seed=4)
+    else:
+        I, Q = siggen.make_iq(nch, nfr * L, nco, mode=mode, seed=6)
+    I, Q = siggen.fade(I, Q, [(0.3, 2.0), (0.3, 0.05), (0.4, 1.5)])
+    flo, fhi = {0: (200, 3000), 2: (-3000, 3000), 3: (200, 3000)}[mode]
+    kw = dict(mode=mode, AGCMode=agcmode, FLoCut=flo, FHiCut=fhi)
+    whole, rx_w = gpu_run(T, kw, nco, I, Q)                                             # one pipelined call
+    short, rx_s = gpu_run(T, kw, nco, I, Q, split=[0, 3 * L, 6 * L, 9 * L, 12 * L, 14 * L])  # barrier form only
+    mixed, rx_m = gpu_run(T, kw, nco, I, Q, split=[0, 4 * L, 5 * L, 14 * L])              # pipelined, barrier, pipelined
+    assert np.isfinite(whole).all()
+    assert np.array_equal(whole, short) and np.array_equal(whole, mixed)
+    assert np.array_equal(rx_w.get_state(), rx_s.get_state()) and np.array_equal(rx_w.get_state(), rx_m.get_state())
+    ref = oracle_run(kw, nco, I, Q)
+    err = siggen.block_rel_err(whole, ref, L)
+    assert err.max() <= (AM_TOL if mode == 2 else TOL), err.max()
+
+
 def test_agc_mode_change_and_reset(T):
     """AGCMode is a parameter like the filter edges: switching it mid-stream keeps the delay line and
     the gain state (the firmware only re-runs AGCLoadValues()), reset() returns to power-on"""

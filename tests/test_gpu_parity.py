@@ -183,7 +183,8 @@ def test_parity_agc(T, agcmode, mode, nfr, segs):
     assert np.array_equal(got, split)
 
 
-@pytest.mark.parametrize("nch,mode,agcmode", [(5, 0, 1), (21, 2, 3), (37, 3, 4), (64, 0, 2)], ids=["5ch-usb", "21ch-am", "37ch-nfm", "64ch-usb"])
+@pytest.mark.parametrize("nch,mode,agcmode", [(1, 0, 1), (5, 0, 1), (17, 1, 2), (21, 2, 3), (37, 3, 4), (64, 0, 2)],
+                         ids=["1ch-usb", "5ch-usb", "17ch-lsb", "21ch-am", "37ch-nfm", "64ch-usb"])
 def test_agc_pipelined_equals_barrier_form(T, nch, mode, agcmode):
     """Calls of four frames or more run the pipelined AGC kernel (rx_kernels.hip: agc_prep_pipe -- the chain of one
     frame on a rotating duty wave while the others work on the neighbouring frames), shorter ones the barrier form:
@@ -195,7 +196,7 @@ def test_agc_pipelined_equals_barrier_form(T, nch, mode, agcmode):
     else:
         I, Q = siggen.make_iq(nch, nfr * L, nco, mode=mode, seed=6)
     I, Q = siggen.fade(I, Q, [(0.3, 2.0), (0.3, 0.05), (0.4, 1.5)])
-    flo, fhi = {0: (200, 3000), 2: (-3000, 3000), 3: (200, 3000)}[mode]
+    flo, fhi = {0: (200, 3000), 1: (-3000, -200), 2: (-3000, 3000), 3: (200, 3000)}[mode]
     kw = dict(mode=mode, AGCMode=agcmode, FLoCut=flo, FHiCut=fhi)
     whole, rx_w = gpu_run(T, kw, nco, I, Q)                                             # one pipelined call
     short, rx_s = gpu_run(T, kw, nco, I, Q, split=[0, 3 * L, 6 * L, 9 * L, 12 * L, 14 * L])  # barrier form only

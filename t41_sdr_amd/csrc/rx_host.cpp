@@ -773,9 +773,10 @@ int t41rx_set_state(t41rx_ctx *ctx, const void *host_buf, size_t bytes) {
     for (int k = 0; k < 4; ++k)
       if (!std::isfinite(r[ag + k])) return fail(T41RX_ERR_STATE, "checkpoint: AGC levels not finite");
     // AMDecodeSAM's statics (Demod.cpp:19-23): the kernel wraps phzerror with one conditional step
-    // each way, which is the reference's pair of `while` loops only for a phase already in [0, 2 pi)
+    // each way, which is the reference's pair of `while` loops only for a phase already in [0, 2 pi] (2 pi itself is
+    // what a tiny negative phase + 2 pi rounds to: the loops leave it, and so does the kernel)
     const float phz = r[kStMisc + kMiscSamPhz], fil = r[kStMisc + kMiscSamFil], om = r[kStMisc + kMiscSamOmega];
-    if (!(phz >= 0.0f && phz < 6.2831855f) || !std::isfinite(fil) || !(std::fabs(fil) < 4.0f) || !(std::fabs(om) <= 1.05f))
+    if (!(phz >= 0.0f && phz <= 6.2831855f) || !std::isfinite(fil) || !(std::fabs(fil) < 4.0f) || !(std::fabs(om) <= 1.05f))
       return fail(T41RX_ERR_STATE, "checkpoint: synchronous-detector PLL words out of range");
   }
   DeviceGuard g(ctx->device);

@@ -713,6 +713,17 @@ __device__ __forceinline__ SamIdx sam_table_index(float in) {
   }
   return SamIdx{index, findex - (float)index};
 }
+// The same for 0 <= in < 2, where the PLL keeps its arguments (phase in [0, 2 pi] times 0.159154943092f <= 1.0000001,
+// + 0.25 for the cosine): there n = (int)in is 0 or 1 and in - n exact, i.e. v_fract_f32; `in < 0` never holds; and
+// 512 (in - n) <= 512 - 2^-15 < 512, so the index never reaches 512 and the wrap is dead code.  Same index, same
+// fraction, 5 instructions instead of 14 (checked against the form above on every float of the range:
+// tests/test_sam.py::test_pll_table_index_short_form).
+__device__ __forceinline__ SamIdx sam_table_index_pos(float in) {
+#pragma clang fp contract(off)
+  const float findex = 512.0f * __builtin_amdgcn_fractf(in);
+  const unsigned index = (unsigned)findex;
+  return SamIdx{index, findex - (float)index};
+}
 __device__ __forceinline__ float sam_atan(float z) {  // ApproxAtan, Utility.cpp:298-302
 #pragma clang fp contract(off)
   const float n1 = 0.97239411f, n2 = -0.19194795f;
@@ -740,7 +751,8 @@ __device__ __forceinline__ void sam_chain(float *zs, const float *T, float *ms, 
   // products, arctangent (an IEEE division) and loop filter run: two independent dependency chains per iteration
   // instead of one twice as long.  Same operations on the same values as the loop as written.
   auto sincos = [&](float ph, float &Sin, float &Cos) {
-    const SamIdx is = sam_table_index(ph * 0.159154943092f), ic = sam_table_index(ph * 0.159154943092f + 0.25f);
+    // (0 <= ph <= 2 pi: kept by the wrap below, by the power-on state and by t41rx_set_state's check)
+    const SamIdx is = sam_table_index_pos(ph * 0.159154943092f), ic = sam_table_index_pos(ph * 0.159154943092f + 0.25f);
     const float sa = T[is.index], sb = T[is.index + 1], ca = T[ic.index], cb = T[ic.index + 1];
     Sin = (1.0f - is.fract) * sa + is.fract * sb;
     Cos = (1.0f - ic.fract) * ca + ic.fract * cb;
@@ -762,8 +774,7 @@ __device__ __forceinline__ void sam_chain(float *zs, const float *T, float *ms, 
     zs[2 * i] = audio;
     const float det = sam_atan2(corr1, corr0);
     omega2 = omega2 + g2 * det;
-    if (omega2 < omega_min) omega2 = omega_min;
-    else if (omega2 > omega_max) omega2 = omega_max;
+    omega2 = __builtin_amdgcn_fmed3f(omega2, omega_min, omega_max);  // Demod.cpp's if / else-if clamp (omega_min < omega_max, no NaNs): one instruction, no branches
     fil_out = g1 * det + omega2;
     phzerror = phznext;
     Sin = SinN;

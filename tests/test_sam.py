@@ -43,6 +43,40 @@ def test_fast_sine_restatement(built):
     assert np.abs(s - s64).max() < 2e-6
 
 
+def test_pll_table_index_short_form():
+    """rx_kernels.hip: sam_table_index_pos() -- arm_sin_f32's index arithmetic for 0 <= x < 2, where the kernel's PLL keeps
+    its arguments, in 5 instructions (x - floor(x), times 512, truncate) -- against the form as CMSIS writes it, on EVERY
+    float32 of [0, 1.26] (what phase * 0.159154943092f and + 0.25f can give for a phase in [0, 2 pi]) and a sample up to 2"""
+    def as_written(x):
+        n = x.astype(np.int32)            # (int32_t) in: truncation
+        n = np.where(x < 0, n - 1, n)
+        fr = x - n.astype(np.float32)
+        findex = np.float32(512.0) * fr
+        idx = findex.astype(np.uint32) & np.uint32(0xffff)
+        wrap = idx >= 512
+        idx = np.where(wrap, np.uint32(0), idx)
+        findex = np.where(wrap, findex - np.float32(512.0), findex)
+        return idx, findex - idx.astype(np.float32)
+
+    def short(x):
+        findex = np.float32(512.0) * (x - np.floor(x))   # v_fract_f32
+        idx = findex.astype(np.uint32)
+        return idx, findex - idx.astype(np.float32)
+
+    hi = np.float32(1.26).view(np.uint32)
+    step = 1 << 24
+    for lo in range(0, int(hi) + 1, step):
+        x = np.arange(lo, min(lo + step, int(hi) + 1), dtype=np.uint32).view(np.float32)
+        (ia, fa), (ib, fb) = as_written(x), short(x)
+        assert np.array_equal(ia, ib) and np.array_equal(fa.view(np.uint32), fb.view(np.uint32)), lo
+    x = np.random.default_rng(5).uniform(1.26, 2.0, 1 << 22).astype(np.float32)
+    (ia, fa), (ib, fb) = as_written(x), short(x)
+    assert np.array_equal(ia, ib) and np.array_equal(fa, fb)
+    # the largest arguments the PLL can form: phase = 2 pi (a tiny negative phase + 2 pi rounds to it)
+    top = np.float32(6.2831855) * np.float32(0.159154943092)
+    assert top < 2 and top + np.float32(0.25) < 2
+
+
 def test_pll_constants(built):
     out = (C.c_float * 4)()
     _lib().t41o_sam_constants(out)

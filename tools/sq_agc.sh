@@ -1,5 +1,9 @@
+#!/bin/bash
+# GPU box: the two SQ utilisation passes of tools/profile_round.sh for the ssb_agc workload (the pipelined AGC kernel);
+# prints the per-dispatch means (profiles/r03_pmc_sq_ssb_agc.txt)
 export TMPDIR=/tmp
-ROOT=${GRAFT_REPO_ROOT}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+export GRAFT_REPO_ROOT=$ROOT
 OUT=$ROOT/gpurun_out/sq_agc
 mkdir -p $OUT
 cd /tmp

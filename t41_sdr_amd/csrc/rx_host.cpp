@@ -593,7 +593,8 @@ int process_device_impl(t41rx_ctx *ctx, const float *dI, const float *dQ, float 
     a.seg_run = (int)(run < 1 ? 1 : (run > 8 ? 8 : (run > segs ? segs : run)));
   }
   a.agc = ctx->params.AGCMode != 0 ? 1 : 0;
-  if (a.agc && seg == 1 && ctx->params.mode != T41RX_DEMOD_SAM && n_frames >= 4) {
+  // the pipelined kernels' slots: AGC on (every mode but SAM), or the synchronous detector with the AGC off
+  if ((a.agc != 0) != (ctx->params.mode == T41RX_DEMOD_SAM) && seg == 1 && n_frames >= 4) {
     if (!ctx->d_agc_pipe) {  // (+ 8 counters per wave of the -DT41RX_PIPE_STAT diagnostic build)
       const size_t bytes = (size_t)ctx->nchan * 3 * 1024 * sizeof(float) + ((size_t)ctx->nchan + 16) * 16 * sizeof(unsigned long long);
       HIP_TRY(hipMalloc((void **)&ctx->d_agc_pipe, bytes));

@@ -739,29 +739,33 @@ __device__ __forceinline__ float sam_atan2(float y, float x) {  // ApproxAtan2, 
   const float r0 = y > 0.0f ? kTpi : (y < 0.0f ? -kTpi : 0.0f);  // x == 0
   return x != 0.0f ? (xg ? rx : ry) : r0;
 }
-__device__ __forceinline__ void sam_chain(float *zs, const float *T, float *ms, CoefPtr cf0, bool store) {
+// AMDecodeSAM's loop for one channel per lane: the PLL's state and one step.
+// The phase of step i + 1 is phase_i + fil_out_(i-1): it does not wait for step i's detector.  So the sine / cosine
+// of the NEXT step (index arithmetic, four table reads, two interpolations) are evaluated while this step's
+// products, arctangent (an IEEE division) and loop filter run: two independent dependency chains per iteration
+// instead of one twice as long.  Same operations on the same values as the loop as written.
+struct SamPll {
+  const float *T;  // arm_sin_f32's table (LDS)
+  float omega_min, omega_max, g1, g2;
+  float phzerror, fil_out, omega2, Sin, Cos;
+  __device__ __forceinline__ void sincos(float ph, float &S, float &C) const {
 #pragma clang fp contract(off)
-  const float kTpi = 6.283185307179586476925286766559f;
-  const CoefPtr c = fresh_coef(cf0);
-  const float omega_min = c->sc[kScSamWmin], omega_max = c->sc[kScSamWmax], g1 = c->sc[kScSamG1], g2 = c->sc[kScSamG2];
-  float phzerror = ms[kMiscSamPhz], fil_out = ms[kMiscSamFil], omega2 = ms[kMiscSamOmega];
-  cf zn = *reinterpret_cast<const cf *>(zs);
-  // The phase of step i + 1 is phase_i + fil_out_(i-1): it does not wait for step i's detector.  So the sine / cosine
-  // of the NEXT step (index arithmetic, four table reads, two interpolations) are evaluated while this step's
-  // products, arctangent (an IEEE division) and loop filter run: two independent dependency chains per iteration
-  // instead of one twice as long.  Same operations on the same values as the loop as written.
-  auto sincos = [&](float ph, float &Sin, float &Cos) {
     // (0 <= ph <= 2 pi: kept by the wrap below, by the power-on state and by t41rx_set_state's check)
     const SamIdx is = sam_table_index_pos(ph * 0.159154943092f), ic = sam_table_index_pos(ph * 0.159154943092f + 0.25f);
     const float sa = T[is.index], sb = T[is.index + 1], ca = T[ic.index], cb = T[ic.index + 1];
-    Sin = (1.0f - is.fract) * sa + is.fract * sb;
-    Cos = (1.0f - ic.fract) * ca + ic.fract * cb;
-  };
-  float Sin, Cos;
-  sincos(phzerror, Sin, Cos);
-  for (int i = 0; i < 256; ++i) {
-    const cf z = zn;
-    if (i < 255) zn = *reinterpret_cast<const cf *>(zs + 2 * i + 2);  // ahead of the dependent chain
+    S = (1.0f - is.fract) * sa + is.fract * sb;
+    C = (1.0f - ic.fract) * ca + ic.fract * cb;
+  }
+  __device__ __forceinline__ void load(const float *Tab, const float *ms, CoefPtr cf0) {
+    const CoefPtr c = fresh_coef(cf0);
+    T = Tab;
+    omega_min = c->sc[kScSamWmin], omega_max = c->sc[kScSamWmax], g1 = c->sc[kScSamG1], g2 = c->sc[kScSamG2];
+    phzerror = ms[kMiscSamPhz], fil_out = ms[kMiscSamFil], omega2 = ms[kMiscSamOmega];
+    sincos(phzerror, Sin, Cos);
+  }
+  __device__ __forceinline__ float step(cf z) {  // Demod.cpp:69-117 for one sample; returns the audio
+#pragma clang fp contract(off)
+    const float kTpi = 6.283185307179586476925286766559f;
     float phznext = phzerror + fil_out;  // (fil_out: still the previous step's = this step's del_out)
     // (the source's two `while` loops: |del_out| <= g1 (2 pi + pi / 4) + omega_max < 1.2, so one pass each)
     if (phznext >= kTpi) phznext -= kTpi;
@@ -771,7 +775,6 @@ __device__ __forceinline__ void sam_chain(float *zs, const float *T, float *ms, 
     const float ai = Cos * z.x, bi = Sin * z.x, aq = Cos * z.y, bq = Sin * z.y;
     const float corr0 = +ai + bq, corr1 = -bi + aq;
     const float audio = (ai - bi) + (aq + bq);
-    zs[2 * i] = audio;
     const float det = sam_atan2(corr1, corr0);
     omega2 = omega2 + g2 * det;
     omega2 = __builtin_amdgcn_fmed3f(omega2, omega_min, omega_max);  // Demod.cpp's if / else-if clamp (omega_min < omega_max, no NaNs): one instruction, no branches
@@ -779,12 +782,25 @@ __device__ __forceinline__ void sam_chain(float *zs, const float *T, float *ms, 
     phzerror = phznext;
     Sin = SinN;
     Cos = CosN;
+    return audio;
   }
-  if (store) {
+  __device__ __forceinline__ void store(float *ms) const {
     ms[kMiscSamPhz] = phzerror;
     ms[kMiscSamFil] = fil_out;
     ms[kMiscSamOmega] = omega2;
   }
+};
+// zs = the channel's 256 complex samples (audio replaces the real parts), T = arm_sin_f32's table in LDS, ms = the channel's kStMisc words
+__device__ __forceinline__ void sam_chain(float *zs, const float *T, float *ms, CoefPtr cf0, bool store) {
+  SamPll pll;
+  pll.load(T, ms, cf0);
+  cf zn = *reinterpret_cast<const cf *>(zs);
+  for (int i = 0; i < 256; ++i) {
+    const cf z = zn;
+    if (i < 255) zn = *reinterpret_cast<const cf *>(zs + 2 * i + 2);  // ahead of the dependent chain
+    zs[2 * i] = pll.step(z);
+  }
+  if (store) pll.store(ms);
 }
 
 template <typename AL>
@@ -1220,6 +1236,71 @@ __device__ __forceinline__ void agc_gain_pipe(const AgcGainIn &in, CoefPtr cf0, 
   }
 }
 
+// ---- the synchronous detector (AGC off) on the same pipeline: the PLL of frame g on the duty wave, one lane per
+// channel.  Slot: the frame's 256 complex samples (fixed gain applied) in time order [512] | the audio [256].
+// The duty wave's scratch holds arm_sin_f32's table (read from the L2-resident constant table per chain: the
+// resident geometry has no LDS for it) and the 16 channels' chunk of 16 samples.
+// Measured (4096 channels): 72.6 -> 67.0 us per frame at 32 frames per launch, 74.5 -> 71.1 at 8: the loop itself is
+// what binds (~510 cycles per step on one wave; here it shares its SIMD and the LDS pipe with three busy waves and
+// runs ~65 us per frame), the pipeline only takes the other waves' 20 us off the path.
+constexpr int kPipeSamZ = 520, kPipeSamStride = 36;  // stage: table [516 + pad] | per channel 16 complex + 4 pad
+constexpr int kPipeSamStageFloats = kPipeSamZ + 16 * kPipeSamStride;
+__device__ __forceinline__ void sam_prep_pipe(const cf (&v)[8], float fixed_gain, float *slot, int lane) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) *reinterpret_cast<cf *>(slot + 2 * (lane + 64 * j)) = v[4 + j] * splat(fixed_gain);
+}
+//   grp : slot (frame g) of the workgroup's first channel; ms0 : its kStMisc words, channel c's stride floats further
+__device__ __forceinline__ void sam_chain_pipe(float *grp, float *ms0, size_t stride, float *stage, const float *tab, const unsigned *done,
+                                               unsigned g, int nvalid, CoefPtr cf0, int lane) {
+  const int ch = (nvalid == 16) ? (lane & 15) : (lane & 15) % nvalid;
+  const int q = lane >> 4;
+  float *gsrc = grp + (size_t)ch * (kPipeSlots * kPipeSlotFloats);
+  float *sw = stage + kPipeSamZ + ch * kPipeSamStride;
+  constexpr int AH = T41RX_PIPE_AHEAD;
+  float4 p0[AH], p1[AH];  // a chunk = 16 complex = 8 float4 per channel: this lane moves float4 q and q + 4
+#pragma unroll
+  for (int u = 0; u < AH; ++u) {
+    p0[u] = *reinterpret_cast<const float4 *>(gsrc + 32 * u + 4 * q);
+    p1[u] = *reinterpret_cast<const float4 *>(gsrc + 32 * u + 16 + 4 * q);
+  }
+  wave_sync();
+  for (int i = lane; i < 516; i += 64) stage[i] = tab[i];
+  pipe_wait_ge(done, g);  // the previous frame's loop has left the PLL words
+  wave_sync();
+  float *ms = ms0 + (size_t)ch * stride;
+  SamPll pll;
+  pll.load(stage, ms, cf0);
+#pragma nounroll
+  for (int k = 0; k < 16; ++k) {
+    {
+      const float4 a0 = p0[0], a1 = p1[0];
+#pragma unroll
+      for (int u = 0; u + 1 < AH; ++u) {
+        p0[u] = p0[u + 1];
+        p1[u] = p1[u + 1];
+      }
+      if (k + AH < 16) {
+        p0[AH - 1] = *reinterpret_cast<const float4 *>(gsrc + 32 * (k + AH) + 4 * q);
+        p1[AH - 1] = *reinterpret_cast<const float4 *>(gsrc + 32 * (k + AH) + 16 + 4 * q);
+      }
+      wave_sync();
+      *reinterpret_cast<float4 *>(sw + 4 * q) = a0;
+      *reinterpret_cast<float4 *>(sw + 16 + 4 * q) = a1;
+      wave_sync();
+    }
+    cf zn = *reinterpret_cast<const cf *>(sw);
+#pragma nounroll
+    for (int i = 0; i < 16; ++i) {
+      const cf z = zn;
+      if (i < 15) zn = *reinterpret_cast<const cf *>(sw + 2 * i + 2);
+      sw[2 * i] = pll.step(z);  // (every lane of a channel writes the same)
+    }
+    wave_sync();
+    *reinterpret_cast<float4 *>(gsrc + 512 + 16 * k + 4 * q) = make_float4(sw[8 * q], sw[8 * q + 2], sw[8 * q + 4], sw[8 * q + 6]);
+  }
+  if (lane < nvalid) pll.store(ms);
+}
+
 constexpr int kModeSsb = 0, kModeAm = 1, kModeNfm = 2, kModeSam = 3;  // kernel template MODE
 // the 4-wave geometry (Geo's second parameter): AGC on, and the synchronous detector, whose PLL is a serial
 // chain run by one wave per workgroup like the AGC's
@@ -1300,7 +1381,9 @@ static_assert(!Geo<0>::kResident || (Geo<0>::kH1 + 24 <= Geo<0>::kSlice && Geo<0
 template <int MODE, bool DEBUG, int PART, bool PLAIN, bool AGC = false, bool WQ15 = false, bool SEGPAR = false, bool PIPE = false>
 __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64), 4) void rx512_kernel(const RxArgs a) {
   static_assert(!SEGPAR || (PART == 1 && MODE != kModeNfm) || (PART == 2 && MODE == kModeSsb && !AGC), "SEGPAR variants");
-  static_assert(!PIPE || (AGC && PART == 0 && MODE != kModeSam && !DEBUG && !SEGPAR && T41RX_RESIDENT), "PIPE: the pipelined AGC variant (see agc_prep_pipe)");
+  static_assert(!PIPE || ((AGC != (MODE == kModeSam)) && PART == 0 && !DEBUG && !SEGPAR && T41RX_RESIDENT),
+                "PIPE: the pipelined variants -- AGC on (see agc_prep_pipe), or the synchronous detector with the AGC off (sam_chain_pipe)");
+  constexpr bool PSAM = PIPE && MODE == kModeSam;
   typedef Geo<PART, geo4(MODE, AGC) && !PIPE> G;
   constexpr bool KEEP = G::kResident;  // streaming state stays on chip across the frames of a launch
   constexpr int NW = G::kWaves;
@@ -1467,7 +1550,7 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
     const float *__restrict__ gQ = a.Q + (WQ15 ? fbase / 2 : fbase);
     float *__restrict__ gO = a.out + (WQ15 ? fbase_o / 2 : fbase_o);
 
-    constexpr bool CONTIG = (MODE == kModeAm) || (AGC && MODE != kModeSam);  // aud[j] = sample 4 lane + j instead of lane + 64 j
+    constexpr bool CONTIG = (MODE == kModeAm) || (AGC && MODE != kModeSam) || PSAM;  // aud[j] = sample 4 lane + j instead of lane + 64 j
     float aud[4];                            // 4 demodulated samples @24 kS/s
     float4 agst = make_float4(0, 0, 0, 0);   // AGC record (delay line + state words), one float4 per lane
     float4 hist1 = make_float4(0, 0, 0, 0);  // x2 interpolator history (lanes 0..5)
@@ -2264,10 +2347,13 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
         const bool early = f >= seg0 + kSkew && pipe_flag_read(flags + 3) >= (unsigned)(fb + 1);
         if (early) {
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-          gin = agc_gain_request<NEED_IM>(bslot, lane);
+          if (PSAM) gin.vv = *reinterpret_cast<const float4 *>(bslot + 512 + 4 * lane);  // the frame's audio
+          else gin = agc_gain_request<NEED_IM>(bslot, lane);
         }
         if (f < seg1) {  // this frame's chain operands and popped samples -> the channel's slot
-          agrec = agc_prep_pipe<AgcLds<true>, NEED_IM>(v, agrec, lds, a.agc_pipe + ((size_t)ch * kPipeSlots + f % kPipeSlots) * kPipeSlotFloats, cf0, lane);
+          float *pslot = a.agc_pipe + ((size_t)ch * kPipeSlots + f % kPipeSlots) * kPipeSlotFloats;
+          if (PSAM) sam_prep_pipe(v, fixed_gain, pslot, lane);
+          else agrec = agc_prep_pipe<AgcLds<true>, NEED_IM>(v, agrec, lds, pslot, cf0, lane);
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
           if (lane == 0) __hip_atomic_fetch_add(flags + f % kPipeSlots, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #ifdef T41RX_PIPE_STAT
@@ -2284,9 +2370,14 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
           if (lane == 0) __hip_atomic_store(flags + g % kPipeSlots, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           const size_t ch0 = (size_t)NW * blockIdx.x;
           PRIO(3);  // the critical path of the whole workgroup, one dependent instruction at a time
-          static_assert(!PIPE || (NW == 16 && kScr + kPipeStageFloats <= G::kXF), "chain staging: 16 channels, inside the X scratch");
-          agc_chain_pipe(a.agc_pipe + (ch0 * kPipeSlots + g % kPipeSlots) * kPipeSlotFloats, a.state + ch0 * state_stride + st_agc(512) + kAgcHistFloats,
-                         state_stride, lds + kScr, flags + 3, (unsigned)g, nvalid, cf0, lane, pipe_stat);
+          static_assert(!PIPE || (NW == 16 && kScr + kPipeStageFloats <= G::kXF && kScr + kPipeSamStageFloats <= G::kXF),
+                        "chain staging: 16 channels, inside the X scratch");
+          if (PSAM)
+            sam_chain_pipe(a.agc_pipe + (ch0 * kPipeSlots + g % kPipeSlots) * kPipeSlotFloats, a.state + ch0 * state_stride + kStMisc, state_stride,
+                           lds + kScr, reinterpret_cast<const float *>(a.tab + kTabSam), flags + 3, (unsigned)g, nvalid, cf0, lane);
+          else
+            agc_chain_pipe(a.agc_pipe + (ch0 * kPipeSlots + g % kPipeSlots) * kPipeSlotFloats, a.state + ch0 * state_stride + st_agc(512) + kAgcHistFloats,
+                           state_stride, lds + kScr, flags + 3, (unsigned)g, nvalid, cf0, lane, pipe_stat);
           PRIO(1);
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
           if (lane == 0) __hip_atomic_store(flags + 3, (unsigned)(g + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -2296,19 +2387,26 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
           PIPE_STAT_T0();
           pipe_wait_ge(flags + 3, (unsigned)(fb + 1));
           PIPE_STAT_ADD(3);
-          gin = agc_gain_request<NEED_IM>(bslot, lane);
+          if (PSAM) gin.vv = *reinterpret_cast<const float4 *>(bslot + 512 + 4 * lane);
+          else gin = agc_gain_request<NEED_IM>(bslot, lane);
         }
 #ifdef T41RX_PIPE_STAT
         ps_t = __builtin_readcyclecounter();
 #endif
-        agc_gain_pipe(gin, cf0, og);
+        if (PSAM) {
+          aud[0] = gin.vv.x, aud[1] = gin.vv.y, aud[2] = gin.vv.z, aud[3] = gin.vv.w;
+        } else {
+          agc_gain_pipe(gin, cf0, og);
+        }
         if (KEEP) hist2 = hist2c;
       } else if (AGC) {
         const int left = a.nchan - NW * (int)blockIdx.x;
         agc_apply<AgcLds<KEEP>, NW, G::kSlice>(v, agst, lds, smem + G::kTab, st + st_agc(512 * seg), cf0, lane, wv,
                                                left < NW ? left : NW, og STAMP_ARGS);
       }
-      if (MODE == kModeSam) {
+      if (PSAM) {
+        // (the audio came out of the slot above)
+      } else if (MODE == kModeSam) {
         // ---- synchronous AM, AMDecodeSAM() Demod.cpp:40-139: a PLL, one sample at a time.  Every wave
         // puts its channel's 256 complex samples in its slice in time order; wave 0 then runs the
         // loops of the workgroup's channels, one lane per channel (all lanes enabled, as in
@@ -2689,7 +2787,7 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
     reinterpret_cast<unsigned long long *>(a.dbg_demod + (size_t)a.nchan * a.nframes * D)[(size_t)ch * 64 + lane] = stamp_acc;
 #endif
 
-  if (PIPE && lane < 50) *reinterpret_cast<float4 *>(st + st_agc(512) + 4 * lane) = agrec;
+  if (PIPE && AGC && lane < 50) *reinterpret_cast<float4 *>(st + st_agc(512) + 4 * lane) = agrec;
   if (KEEP) {  // the channel's record goes back to HBM once per launch
     wave_sync();
     if (lane < 14) *reinterpret_cast<float4 *>(st + kStDec1 + 4 * lane) = lds4(lds + kX + 2 * xpad(2 * lane));
@@ -3960,6 +4058,16 @@ hipError_t launch_rx(const RxArgs &a, int fft_length, int mode, hipStream_t s) {
     case T41RX_DEMOD_NFM:
       return launch512<kModeNfm>(a, s, debug);
     case T41RX_DEMOD_SAM: {  // the general front end
+      static const bool pipe_env = [] {
+        const char *e = std::getenv("T41RX_AGC_PIPE");
+        return !e || std::atoi(e) != 0;
+      }();
+      if (!a.agc && a.agc_pipe && !debug && a.nframes >= 4 && pipe_env) {  // the PLL pipelined against the neighbouring frames (sam_chain_pipe)
+        const dim3 g16((a.nchan + Geo<0>::kWaves - 1) / Geo<0>::kWaves), b16(Geo<0>::kWaves * 64);
+        if (a.q15) hipLaunchKernelGGL((rx512_kernel<kModeSam, false, 0, false, false, true, false, true>), g16, b16, 0, s, a);
+        else hipLaunchKernelGGL((rx512_kernel<kModeSam, false, 0, false, false, false, false, true>), g16, b16, 0, s, a);
+        return hipGetLastError();
+      }
       const int grid = (a.nchan + 3) / 4;
       if (a.q15) {  // the firmware's sample format either side (no taps: refused by the host)
         if (a.agc) hipLaunchKernelGGL((rx512_kernel<kModeSam, false, 0, false, true, true>), dim3(grid), dim3(256), 0, s, a);

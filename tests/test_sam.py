@@ -192,10 +192,16 @@ def test_gpu_sam_split_and_state(built):
     nch, nfr = 9, 8
     nco = siggen.nco_grid(nch, seed=22)
     I, Q = siggen.make_am_carrier(nch, nfr * L, nco, seed=77)
-    a, rxa = _gpu_run(T, KW, nco, I, Q, [8])
-    b, rxb = _gpu_run(T, KW, nco, I, Q, [3, 1, 4])
+    a, rxa = _gpu_run(T, KW, nco, I, Q, [8])          # one call: the pipelined kernel (sam_chain_pipe, four frames or more)
+    b, rxb = _gpu_run(T, KW, nco, I, Q, [3, 1, 4])    # barrier form, barrier form, pipelined
     assert np.array_equal(a, b)
     assert np.array_equal(rxa.get_state(), rxb.get_state())  # (bytes: the oscillator's phase word is not a float)
+    for n in (1, 21, 37):  # ragged workgroups of the 16-channel pipelined kernel against 3-frame calls (barrier form only)
+        nc = siggen.nco_grid(n, seed=30 + n)
+        Ii, Qi = siggen.make_am_carrier(n, 12 * L, nc, seed=70 + n)
+        w, rxw = _gpu_run(T, KW, nc, Ii, Qi, [12])
+        p, rxp = _gpu_run(T, KW, nc, Ii, Qi, [3, 3, 3, 3])
+        assert np.array_equal(w, p) and np.array_equal(rxw.get_state(), rxp.get_state()), n
     rec = rxa.state_records()
     assert np.abs(rec[:, 184 + 13:184 + 16]).max() > 0  # phzerror / fil_out / omega2 live in the record
     rxa.reset()

@@ -20,9 +20,10 @@ def outputs(tag):
     import torch
     res = {}
     for name, nch, nfr, kw in (("usb21", 21, 9, dict(AGCMode=1)), ("usb64", 64, 36, dict(AGCMode=2)), ("am5", 5, 12, dict(AGCMode=3, mode=2, FLoCut=-3000, FHiCut=3000)),
-                               ("nfm37", 37, 8, dict(AGCMode=4, mode=3, FLoCut=-4000, FHiCut=4000)), ("gains16", 16, 6, dict(AGCMode=1, RFgain=3, IQPhaseCorrectionFactor=0.05))):
+                               ("nfm37", 37, 8, dict(AGCMode=4, mode=3, FLoCut=-4000, FHiCut=4000)), ("gains16", 16, 6, dict(AGCMode=1, RFgain=3, IQPhaseCorrectionFactor=0.05)),
+                               ("sam21", 21, 20, dict(mode=8, FLoCut=-3000, FHiCut=3000)), ("sam64", 64, 9, dict(mode=8, FLoCut=-3000, FHiCut=3000))):
         nco = siggen.nco_grid(nch, seed=3)
-        I, Q = siggen.make_iq(nch, nfr * L, nco, mode=kw.get("mode", 0), seed=7)
+        I, Q = siggen.make_iq(nch, nfr * L, nco, mode=2 if kw.get("mode") == 8 else kw.get("mode", 0), seed=7)
         # level steps so that the gain law walks through its states
         env = np.ones(nfr * L, np.float32)
         env[(nfr * L) // 3:(nfr * L) // 2] = 0.05

@@ -398,6 +398,23 @@ def test_long_stream_phase_and_state_do_not_drift(T):
     assert err[:, -20:].max() <= 3 * max(err[:, 5:25].max(), 2e-7) + 1e-6  # no growth over time
 
 
+def test_long_stream_agc_pipelined(T):
+    """200 frames in ONE call with the AGC on: the pipelined kernel's three-slot ring turns 66 times and the chain's
+    duty goes round the workgroup's waves 10 times (19 channels: a full workgroup and a ragged one of 3); fading drives
+    the gain law through its states the whole way.  Against the oracle, and against the same stream in short calls."""
+    nch, nfr = 19, 200
+    nco = siggen.nco_grid(nch, seed=91)
+    I, Q = siggen.make_iq(nch, nfr * L, nco, seed=92)
+    I, Q = siggen.fade(I, Q, [(0.1, 2.0), (0.15, 0.05), (0.1, 1.0), (0.2, 0.02), (0.15, 2.5), (0.3, 0.3)])
+    kw = dict(mode=0, FLoCut=200, FHiCut=3000, AGCMode=3)
+    got, rx = gpu_run(T, kw, nco, I, Q)
+    ref = oracle_run(kw, nco, I, Q)
+    err = siggen.block_rel_err(got, ref, L)
+    assert np.isfinite(got).all() and err.max() <= TOL, (err.max(), np.unravel_index(err.argmax(), err.shape))
+    short, rx2 = gpu_run(T, kw, nco, I, Q, split=[k * L for k in range(0, nfr + 1, 2)])  # 2-frame calls: the barrier form
+    assert np.array_equal(got, short) and np.array_equal(rx.get_state(), rx2.get_state())
+
+
 def test_filter_and_tuning_change_mid_stream(T):
     """CalcFilters()/NCOFreq change between two ProcessIQData() calls: coefficients change, state
     (delay lines, oscillator phase) is kept -- exactly what the reference does"""

@@ -1026,7 +1026,8 @@ __device__ __forceinline__ void pipe_wait_ge(const unsigned *p, unsigned target)
 
 // first half of agc_apply: magnitudes, look-ahead maxima; what the chain and the gain need -> slot
 template <typename AL, bool NEED_IM>
-__device__ __forceinline__ float4 agc_prep_pipe(const cf (&v)[8], float4 agst, float *lds, float *slot, CoefPtr cf0, int lane) {
+// arec: the delay line's magnitudes (computed a frame ago as that frame's newest: carried, not recomputed)
+__device__ __forceinline__ float4 agc_prep_pipe(const cf (&v)[8], float4 agst, float2 &arec, float *lds, float *slot, CoefPtr cf0, int lane) {
   constexpr int kAgZ = AL::Z, kAgA = AL::A, kAgG = AL::G;
   wave_sync();
   if (lane < 50) *reinterpret_cast<float4 *>(lds + kAgZ + 4 * lane) = agst;
@@ -1035,7 +1036,7 @@ __device__ __forceinline__ float4 agc_prep_pipe(const cf (&v)[8], float4 agst, f
     *reinterpret_cast<cf *>(lds + kAgZ + 2 * (100 + lane + 64 * j)) = v[4 + j];
     lds[kAgA + 100 + lane + 64 * j] = agc_mag(v[4 + j]);
   }
-  if (lane < 50) *reinterpret_cast<float2 *>(lds + kAgA + 2 * lane) = make_float2(agc_mag(cf{agst.x, agst.y}), agc_mag(cf{agst.z, agst.w}));
+  if (lane < 50) *reinterpret_cast<float2 *>(lds + kAgA + 2 * lane) = arec;
   wave_sync();
   {
     float4 t = lds4(lds + kAgA + 4 * lane);
@@ -1066,6 +1067,7 @@ __device__ __forceinline__ float4 agc_prep_pipe(const cf (&v)[8], float4 agst, f
   }
   // the delay line for the next frame: the newest 100 inputs, kept in registers (lanes 0..49; the state words are the chain's)
   const float4 rec = lds4(lds + kAgZ + 512 + 4 * (lane < 50 ? lane : 0));
+  arec = *reinterpret_cast<const float2 *>(lds + kAgA + 256 + 2 * (lane < 50 ? lane : 0));
   wave_sync();
   return rec;
 }
@@ -1487,6 +1489,7 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
   float4 hist1c = make_float4(0, 0, 0, 0);
   float hist2c = 0.0f, audn[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   float4 agrec = make_float4(0, 0, 0, 0);  // PIPE: the AGC's delay line (its last 100 inputs), lanes 0..49, across the frames of a launch
+  float2 agmag = make_float2(0, 0);        // ... and its magnitudes
 #ifdef T41RX_STAMP
   unsigned long long stamp_acc = 0, stamp_last;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
@@ -2353,7 +2356,10 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
         if (f < seg1) {  // this frame's chain operands and popped samples -> the channel's slot
           float *pslot = a.agc_pipe + ((size_t)ch * kPipeSlots + f % kPipeSlots) * kPipeSlotFloats;
           if (PSAM) sam_prep_pipe(v, fixed_gain, pslot, lane);
-          else agrec = agc_prep_pipe<AgcLds<true>, NEED_IM>(v, agrec, lds, pslot, cf0, lane);
+          else {
+            if (first_iter) agmag = make_float2(agc_mag(cf{agrec.x, agrec.y}), agc_mag(cf{agrec.z, agrec.w}));  // (later frames: carried)
+            agrec = agc_prep_pipe<AgcLds<true>, NEED_IM>(v, agrec, agmag, lds, pslot, cf0, lane);
+          }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
           if (lane == 0) __hip_atomic_fetch_add(flags + f % kPipeSlots, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #ifdef T41RX_PIPE_STAT

@@ -163,14 +163,23 @@ __device__ __forceinline__ float wave_sum(float v) {
 template <int KIND>
 __global__ __launch_bounds__(64) void nrspec_kernel(const NrArgs a) {
 #pragma clang fp contract(off)
-  __shared__ __attribute__((aligned(16))) float xbuf[8 * kFftRow * 2];  // FFT exchange
+  // One region serves, one after the other within a frame, as the FFT's exchange buffer, the spectrum for the partner
+  // access, the two weighted spectra and the two output frames: a workgroup is ONE wave, whose LDS operations execute
+  // in program order, and each tenant is dead (in registers) before the next one is written.  With the per-bin
+  // memories that leaves the spectral function under 10 KiB, i.e. 16 workgroups per CU: the whole 4096-channel batch
+  // resident in one round instead of two.
+  __shared__ __attribute__((aligned(16))) float U[8 * kFftRow * 2];
+  static_assert(8 * kFftRow * 2 >= 520 && 8 * kFftRow * 2 >= 512, "tenants of the shared region");
+  float *xbuf = U;                               // FFT exchange
+  cf *Zs = reinterpret_cast<cf *>(U);            // [257] the 256-point spectrum of frame 0 + j frame 1 (partner access), [256] = [0]
+  cf *W0 = reinterpret_cast<cf *>(U), *W1 = reinterpret_cast<cf *>(U + 260);  // [129] each: weighted, conjugate-symmetrised spectra, bins 0..128
+  float *Y0 = U, *Y1 = U + 256;                  // [256] each
   __shared__ float S[384];          // NR_last_sample_buffer_L | the block's 256 samples
-  __shared__ cf Zs[257];            // the 256-point spectrum of frame 0 + j frame 1 (partner access), [256] = [0]
-  __shared__ cf W0[129], W1[129];   // weighted, conjugate-symmetrised spectra of the two frames, bins 0..128
-  __shared__ float Y0[256], Y1[256];
   __shared__ float Gb[130];         // gains with one pad either side: Gb[1 + i]
-  __shared__ float Xs[KIND == 1 ? 3 : 1][128], Es[KIND == 1 ? 15 : 1][128];  // Kim1_NR()'s frame histories
-  __shared__ float Gts1[128], Gts0[128], Gst[128], Lout[128], Nest[128], Pslp[128], Xt[128], Hk[128];
+  constexpr int KW = (KIND == 1) ? 128 : 1;  // (Kim1_NR()'s memories only)
+  __shared__ float Xs[KIND == 1 ? 3 : 1][KW], Es[KIND == 1 ? 15 : 1][KW];  // Kim1_NR()'s frame histories
+  __shared__ float Gts1[KW], Gts0[KW];
+  __shared__ float Gst[128], Lout[128], Nest[128], Pslp[128], Xt[128], Hk[128];
   const int lane = threadIdx.x;
   const int ch = blockIdx.x;
   if (ch >= a.nchan) return;
@@ -189,8 +198,10 @@ __global__ __launch_bounds__(64) void nrspec_kernel(const NrArgs a) {
     for (int i = lane; i < 15 * 128; i += 64) (&Es[0][0])[i] = st[kNrE + i];
   }
   for (int i = lane; i < 128; i += 64) {
-    Gts1[i] = st[kNrGts1 + i];
-    Gts0[i] = st[kNrGts0 + i];
+    if (KIND == 1) {
+      Gts1[i] = st[kNrGts1 + i];
+      Gts0[i] = st[kNrGts0 + i];
+    }
     Gst[i] = st[kNrG + i];
     S[i] = st[kNrLastIn + i];
     Lout[i] = st[kNrLastOut + i];
@@ -492,8 +503,10 @@ __global__ __launch_bounds__(64) void nrspec_kernel(const NrArgs a) {
     for (int i = lane; i < 15 * 128; i += 64) st[kNrE + i] = (&Es[0][0])[i];
   }
   for (int i = lane; i < 128; i += 64) {
-    st[kNrGts1 + i] = Gts1[i];
-    st[kNrGts0 + i] = Gts0[i];
+    if (KIND == 1) {
+      st[kNrGts1 + i] = Gts1[i];
+      st[kNrGts0 + i] = Gts0[i];
+    }
     st[kNrG + i] = Gst[i];
     st[kNrLastIn + i] = S[i];
     st[kNrLastOut + i] = Lout[i];

@@ -1,0 +1,158 @@
+"""A model of the pipelined AGC / SAM kernel's hand-over protocol (rx_kernels.hip: agc_prep_pipe and the PIPE block of
+rx512_kernel): 16 waves of one workgroup, each running the program
+
+    for f in 0 .. F + 1:
+        if f < F:   front end + preparation of frame f  -> writes slot f % 3, ready[f % 3] += 1
+        g = f - 1:  if 0 <= g < F and g % nvalid == wave: wait ready[g % 3] == nvalid, reset it, (request the first
+                    operands,) wait done == g, run the chain of g (reads / writes slot g % 3), done = g + 1
+        h = f - 2:  if h >= 0: wait done > h, back end of h (reads slot h % 3)
+
+with arbitrary (random) durations of every phase.  Checked on many random schedules: it terminates (no wave waits for
+something that cannot happen), a chain sees every channel's operands and its predecessor's state, a back end sees its
+chain's results, no slot is overwritten while a chain or a back end may still read it, and the reset of a ready counter
+never swallows an increment that belongs to a later frame."""
+import heapq
+import random
+
+import pytest
+
+
+def simulate(nvalid, F, rng, chain_cost, front_cost, back_cost):
+    ready = [0, 0, 0]
+    done = 0
+    t_prep_end = [[None] * F for _ in range(nvalid)]       # [wave][frame]
+    t_back = [[(None, None)] * F for _ in range(nvalid)]   # (start, end)
+    t_chain = [(None, None)] * F
+    ready_owner = [[], [], []]                              # which frames' increments a counter currently holds
+    # each wave is a generator of (kind, payload) requests; the scheduler advances the earliest runnable one
+    def program(w):
+        for f in range(F + 2):
+            if f < F:
+                yield ("run", front_cost())
+                yield ("prep_done", f)
+            g = f - 1
+            if 0 <= g < F and g % nvalid == w:
+                yield ("wait_ready", g)
+                yield ("wait_done_eq", g)
+                yield ("chain_begin", g)
+                yield ("run", chain_cost())
+                yield ("chain_end", g)
+            h = f - 2
+            if h >= 0:
+                yield ("wait_done_gt", h)
+                yield ("back_begin", h)
+                yield ("run", back_cost())
+                yield ("back_end", h)
+
+    progs = [program(w) for w in range(nvalid)]
+    now = [0.0] * nvalid
+    pending = [None] * nvalid            # a blocked request, retried when state changes
+    finished = [False] * nvalid
+    heap = [(0.0, w) for w in range(nvalid)]
+    heapq.heapify(heap)
+    blocked = set()
+    steps = 0
+    while heap:
+        steps += 1
+        assert steps < 2_000_000
+        t, w = heapq.heappop(heap)
+        now[w] = max(now[w], t)
+        progressed = True
+        while progressed:
+            req = pending[w]
+            if req is None:
+                try:
+                    req = next(progs[w])
+                except StopIteration:
+                    finished[w] = True
+                    break
+            pending[w] = None
+            kind, x = req
+            if kind == "run":
+                now[w] += x
+                heapq.heappush(heap, (now[w], w))
+                progressed = False
+            elif kind == "prep_done":
+                f = x
+                # the slot f % 3 was last used by frame f - 3: its chain and THIS wave's back end must be over
+                if f >= 3:
+                    assert t_chain[f - 3][1] is not None and t_chain[f - 3][1] <= now[w], "slot overwritten under a running chain"
+                    assert t_back[w][f - 3][1] is not None and t_back[w][f - 3][1] <= now[w], "slot overwritten before its back end read it"
+                t_prep_end[w][f] = now[w]
+                ready[f % 3] += 1
+                ready_owner[f % 3].append(f)
+            elif kind == "wait_ready":
+                g = x
+                if ready[g % 3] >= nvalid:
+                    assert ready_owner[g % 3] == [g] * nvalid, "a ready counter mixes frames: %r" % (ready_owner[g % 3],)
+                    ready[g % 3] = 0
+                    ready_owner[g % 3] = []
+                else:
+                    pending[w] = req
+                    blocked.add(w)
+                    progressed = False
+            elif kind == "wait_done_eq":
+                if done >= x:
+                    assert done == x
+                else:
+                    pending[w] = req
+                    blocked.add(w)
+                    progressed = False
+            elif kind == "wait_done_gt":
+                if done > x:
+                    pass
+                else:
+                    pending[w] = req
+                    blocked.add(w)
+                    progressed = False
+            elif kind == "chain_begin":
+                g = x
+                assert all(t_prep_end[v][g] is not None and t_prep_end[v][g] <= now[w] for v in range(nvalid)), "chain without every channel's operands"
+                assert g == 0 or t_chain[g - 1][1] <= now[w], "chain before its predecessor's state"
+                t_chain[g] = (now[w], None)
+            elif kind == "chain_end":
+                g = x
+                t_chain[g] = (t_chain[g][0], now[w])
+                done = g + 1
+            elif kind == "back_begin":
+                h = x
+                assert t_chain[h][1] is not None and t_chain[h][1] <= now[w], "back end before its chain's results"
+                t_back[w][h] = (now[w], None)
+            elif kind == "back_end":
+                t_back[w][x] = (t_back[w][x][0], now[w])
+            # a state change may unblock others: they resume no earlier than now
+            if kind in ("prep_done", "chain_end") and blocked:
+                for v in list(blocked):
+                    blocked.discard(v)
+                    heapq.heappush(heap, (max(now[v], now[w]), v))
+    assert all(finished), "deadlock: waves %r never finished" % [w for w in range(nvalid) if not finished[w]]
+    assert done == F
+    return max(now)
+
+
+@pytest.mark.parametrize("nvalid", [1, 2, 3, 5, 16])
+def test_protocol_terminates_and_orders_every_access(nvalid):
+    rng = random.Random(1000 + nvalid)
+    for trial in range(60):
+        F = rng.choice([4, 5, 7, 16, 33])
+        style = trial % 4
+        if style == 0:    # the measured proportions: chain ~60, front ~47, back ~10 (k cycles)
+            costs = (lambda: rng.uniform(55, 65), lambda: rng.uniform(40, 55), lambda: rng.uniform(8, 12))
+        elif style == 1:  # a chain much longer than everything else
+            costs = (lambda: rng.uniform(200, 400), lambda: rng.uniform(1, 50), lambda: rng.uniform(1, 20))
+        elif style == 2:  # a negligible chain, wildly uneven waves
+            costs = (lambda: rng.uniform(0.1, 1), lambda: rng.choice([1, 5, 300]), lambda: rng.choice([1, 100]))
+        else:             # everything random over three decades
+            costs = (lambda: 10 ** rng.uniform(-1, 2), lambda: 10 ** rng.uniform(-1, 2), lambda: 10 ** rng.uniform(-1, 2))
+        simulate(nvalid, F, rng, *costs)
+
+
+def test_two_frames_of_slack_keep_the_duty_waves_lag_off_the_chain_path():
+    """the design's argument: with the measured proportions the frame period is set by the waves' own work
+    plus their share of the chains, not by chain + front end as with one frame of slack"""
+    rng = random.Random(7)
+    F = 64
+    total = simulate(16, F, rng, lambda: 60.0, lambda: 47.0, lambda: 10.0)
+    per_frame = total / F
+    assert per_frame < 0.85 * (60.0 + 47.0), per_frame      # clearly below chain + front end
+    assert per_frame >= 57.0 + 60.0 / 16 - 1e-9             # and no better than a wave's own work + its share of the duty

@@ -987,14 +987,15 @@ __device__ __forceinline__ void agc_apply(const cf (&v)[8], float4 agst, float *
 //     keeps their global accesses in order, so the fences cost an LDS wait and no vmcnt(0).
 // Every value is computed by the same instructions as in agc_apply / agc_chain: bit-identical
 // (tools/agc_pipe_probe.py, tests/test_gpu_parity.py::test_agc_pipelined_equals_barrier_form).
-// Measured (MI355X, 4096 channels x 32 frames, tools/agc_pipe_round.sh, -DT41RX_PIPE_STAT counters):
-// 33 us per frame against 39-40 for the barrier form.  A chain takes 57-64 k cycles (175-200 per
-// step + staging), a wave's front end 38 k, preparation 9 k, back end 10 k wall cycles per frame;
-// the slots cost 8 KiB of fabric traffic per channel-frame on top of the 24 KiB of samples (they
-// miss L2: the 4096-channel working set is 5 MiB per XCD), but removing half of it in a timing
-// experiment bought 5 %: what binds is instruction issue -- the SIMD that hosts the chain carries
-// it (~33 k issue cycles per frame) on top of its four waves' own work while the other three idle
-// part of the time -- and behind that the chain's own latency (~25 us per frame).
+// Measured (MI355X, 4096 channels x 32 frames, tools/agc_pipe_round.sh, -DT41RX_PIPE_STAT counters in shader-clock
+// cycles): 33-34 us per frame against 39-40 for the barrier form.  A chain takes 57-64 k cycles (175-200 per step +
+// staging + ~8 k exposed at its start), a wave's front end 38 k, preparation 9 k, back end 10 k per frame; with
+// the waits and a sixteenth of a chain ~68 k cycles = the measured period at the ~2.1 GHz sustained under this load.
+// The slots cost ~10 KiB of fabric traffic per channel-frame on top of the 24 KiB of samples (they miss L2: the
+// 4096-channel working set is 5 MiB per XCD), but removing half of it in a timing experiment bought 5 %: what binds
+// is the chain's own latency (the protocol's model with these phase lengths: 60 k cycles per frame,
+// tests/test_pipe_protocol_model.py) together with instruction issue (2528 VALU instructions per wave-frame against
+// the AGC-off kernel's 1767 at the same 62 % VALU utilisation: every phase is stretched, the chain included).
 // ------------------------------------------------------------------------------------------
 constexpr int kPipeSlots = 3, kPipeSlotFloats = 1024;  // ring_max -> volts [256] | |popped| [256] | popped re [256] | popped im [256] (AM only)
 constexpr int kPipeFlags = 1008;                        // float index in the table area: ready[3], done

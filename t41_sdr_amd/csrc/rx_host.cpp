@@ -293,8 +293,8 @@ void free_ctx(t41rx_ctx *ctx) {
     std::vector<unsigned long long> all((size_t)ctx->nchan * 16);
     (void)hipMemcpy(all.data(), ctx->d_agc_pipe + (size_t)ctx->nchan * 3 * 1024, all.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
     for (size_t i = 0; i < all.size(); ++i) c[i & 15] += all[i];
-    std::fprintf(stderr, "pipe_stat chain_cycles %llu chains %llu slow_blocks %llu back_wait %llu duty_wait %llu blocks %llu chain_stage %llu chain_steps %llu front %llu prep %llu back %llu wave_iterations %llu\n",
-                 c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8], c[9], c[10], c[11]);
+    std::fprintf(stderr, "pipe_stat chain_cycles %llu chains %llu slow_blocks %llu back_wait %llu duty_wait %llu blocks %llu chain_stage %llu chain_steps %llu front %llu prep %llu back %llu wave_iterations %llu chain_state_wait %llu\n",
+                 c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8], c[9], c[10], c[11], c[12]);
   }
   (void)hipFree(ctx->d_agc_pipe);
   (void)hipFree(ctx->d_in_i);

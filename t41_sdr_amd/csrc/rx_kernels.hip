@@ -1122,6 +1122,10 @@ __device__ __forceinline__ void agc_chain_pipe(float *grp, float *stw0, size_t s
   float *stw = stw0 + (size_t)ch * stride;
   const float4 sf = *reinterpret_cast<const float4 *>(stw);
   const int4 si = *reinterpret_cast<const int4 *>(stw + 4);
+#ifdef T41RX_PIPE_STAT
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0) pipe_stat[12] += __builtin_readcyclecounter() - pipe_t0;  // the state words' (and every older request's) round trip
+#endif
   AgcState st{sf.x, sf.y, sf.z, sf.w, si.x, si.y, si.z};
   AgcLane d = agc_lane_of(st, gc);
 #ifdef T41RX_PIPE_STAT
@@ -1129,7 +1133,7 @@ __device__ __forceinline__ void agc_chain_pipe(float *grp, float *stw0, size_t s
 #endif
   // (rolled loops: one copy of the four-step block -- ~1300 instructions -- instead of sixteen; the register ring
   // of requested chunks rotates by moves.  Measured: the inner loop unrolled, four copies, runs 12 % faster per step
-  // and the kernel 6 % slower -- the other waves' front and back ends share the instruction cache; six chunks ahead
+  // and the kernel 6 % slower (two copies: 1.5 % slower) -- the other waves' front and back ends share the instruction cache; six chunks ahead
   // instead of four spill: 23 % slower)
 #pragma nounroll
   for (int k = 0; k < 256 / kPipeChunk; ++k) {

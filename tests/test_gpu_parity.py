@@ -398,6 +398,20 @@ def test_long_stream_phase_and_state_do_not_drift(T):
     assert err[:, -20:].max() <= 3 * max(err[:, 5:25].max(), 2e-7) + 1e-6  # no growth over time
 
 
+@pytest.mark.parametrize("nfr", [4, 5, 6, 7, 8])
+def test_agc_pipelined_short_calls(T, nfr):
+    """the shortest calls the pipelined kernel takes (its pipeline is two frames deep, its slot ring three): every
+    length from 4 to 8 frames against the barrier form, 19 channels, AM (both slot halves of the popped samples in use)"""
+    nch = 19
+    nco = siggen.nco_grid(nch, seed=60 + nfr)
+    I, Q = siggen.make_iq(nch, (nfr + 2) * L, nco, mode=2, seed=61)
+    I, Q = siggen.fade(I, Q, [(0.5, 1.5), (0.5, 0.1)])
+    kw = dict(mode=2, AGCMode=4, FLoCut=-3000, FHiCut=3000)
+    a, rxa = gpu_run(T, kw, nco, I, Q, split=[0, 2 * L, (nfr + 2) * L])            # barrier (2 frames), then pipelined (nfr)
+    b, rxb = gpu_run(T, kw, nco, I, Q, split=[k * L for k in range(0, nfr + 3)])   # frame by frame: barrier form only
+    assert np.array_equal(a, b) and np.array_equal(rxa.get_state(), rxb.get_state())
+
+
 def test_long_stream_agc_pipelined(T):
     """200 frames in ONE call with the AGC on: the pipelined kernel's three-slot ring turns 66 times and the chain's
     duty goes round the workgroup's waves 10 times (19 channels: a full workgroup and a ragged one of 3); fading drives

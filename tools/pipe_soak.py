@@ -1,0 +1,65 @@
+"""GPU box: soak of the pipelined AGC / SAM kernels (rx_kernels.hip: agc_prep_pipe) against the barrier form, bit for
+bit, on random shapes -- the hand-over between waves rests on the CU's in-order vector memory path and LDS flags; a
+race would show as a mismatch in some run.  One call of n frames (pipelined) against the same stream in calls of at
+most three frames (barrier form), outputs and checkpoints compared; now and then the full 4096 x 32 shape.
+usage: python tools/pipe_soak.py [seconds]"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+L = 2048
+
+
+def main():
+    import torch
+    import t41_sdr_amd as T
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+    rng = np.random.default_rng(int(time.time()))
+    g = torch.Generator(device="cuda").manual_seed(int(rng.integers(1 << 30)))
+    t0, runs, frames, bad, nonfinite = time.time(), 0, 0, [], 0
+    while time.time() - t0 < budget:
+        big = runs % 25 == 24
+        nch = 4096 if big else int(rng.choice([1, 2, 3, 5, 15, 16, 17, 31, 33, 64, 100, 255, 256, 300, 1000]))
+        nfr = 32 if big else int(rng.integers(4, 41))
+        mode = int(rng.choice([0, 1, 2, 3, 8]))
+        agc = 0 if mode == 8 else int(rng.integers(1, 5))
+        flo, fhi = {0: (200, 3000), 1: (-3000, -200), 2: (-3000, 3000), 3: (200, 3000), 8: (-3000, 3000)}[mode]
+        kw = dict(mode=mode, AGCMode=agc, FLoCut=flo, FHiCut=fhi)
+        nco = (rng.integers(-860, 801, nch) * 50).astype(np.int32)
+        # noise with a slow random envelope: the gain law keeps changing state
+        env = torch.rand(nch, nfr * 8, generator=g, device="cuda").repeat_interleave(L // 8, dim=1) ** 3
+        I = (0.3 * env * torch.randn(nch, nfr * L, generator=g, device="cuda")).clamp_(-0.999, 0.999)
+        Q = (0.3 * env * torch.randn(nch, nfr * L, generator=g, device="cuda")).clamp_(-0.999, 0.999)
+        rx1 = T.RxChain(nch, T.default_params(**kw), NCOFreq=nco)
+        whole = rx1.ProcessIQData(I, Q)
+        rx2 = T.RxChain(nch, T.default_params(**kw), NCOFreq=nco)
+        parts, pos = [], 0
+        while pos < nfr:
+            n = min(int(rng.integers(1, 4)), nfr - pos)
+            parts.append(rx2.ProcessIQData(I[:, pos * L:(pos + n) * L].contiguous(), Q[:, pos * L:(pos + n) * L].contiguous()))
+            pos += n
+        short = torch.cat(parts, dim=1)
+        # (bitwise: NFM divides by |z|^2, and an envelope this deep underflows it to 0 now and then -- NaNs, in both forms alike)
+        same = bool(torch.equal(whole.view(torch.int32), short.view(torch.int32))) and bool(np.array_equal(rx1.get_state(), rx2.get_state()))
+        finite = bool(torch.isfinite(whole).all())
+        nonfinite += 0 if finite else 1
+        if not same:
+            bad.append(dict(run=runs, nch=nch, nfr=nfr, kw=kw, same=same, finite=finite))
+            print("MISMATCH", bad[-1], flush=True)
+        runs += 1
+        frames += nch * nfr
+        del rx1, rx2, I, Q, env, whole, short, parts
+        if runs % 20 == 0:
+            print("%d runs, %.1f M channel-frames, %d mismatches, %.0f s" % (runs, frames / 1e6, len(bad), time.time() - t0), flush=True)
+    print(json.dumps({"runs": runs, "channel_frames": frames, "mismatches": len(bad), "runs_with_nonfinite_samples": nonfinite,
+                      "seconds": round(time.time() - t0, 1)}), flush=True)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

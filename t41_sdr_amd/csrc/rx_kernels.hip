@@ -1077,14 +1077,14 @@ __device__ __forceinline__ float4 agc_prep_pipe(const cf (&v)[8], float4 agst, f
 // streaming traffic of fifteen other waves: several microseconds away.  The duty wave therefore moves them through
 // its own LDS scratch (free between its AGC preparation and its back end) in chunks of 16 steps for all the
 // channels at once -- lane (channel, quarter) loads one float4 of ring_max and one of |popped| per chunk --, requested
-// kPipeAhead chunks (64 steps) ahead; the first ones before the wait for the previous frame's chain.
+// T41RX_PIPE_AHEAD chunks ahead; the first ones before the wait for the previous frame's chain.
 //   grp   : slot (frame g) of the workgroup's first channel; channel c's is kPipeSlots * kPipeSlotFloats * c further
 //   stw0  : the eight state words of the workgroup's first channel, channel c's stride floats further
 //   stage : kPipeStageFloats of LDS
 constexpr int kPipeChunk = 16, kPipeChStride = 52;  // per channel in the stage: ring_max -> volts [16] | (b x) pairs [32] | 4 pad
 constexpr int kPipeStageFloats = 16 * kPipeChStride;
 #ifndef T41RX_PIPE_AHEAD
-#define T41RX_PIPE_AHEAD 4
+#define T41RX_PIPE_AHEAD 2  // chunks requested ahead (measured: 1, 2, 3, 4 within 1 %; 6 spills and is 23 % slower)
 #endif
 __device__ __forceinline__ void agc_chain_pipe(float *grp, float *stw0, size_t stride, float *stage, const unsigned *done, unsigned g,
                                                int nvalid, CoefPtr cf0, int lane, unsigned long long *pipe_stat) {
@@ -1133,8 +1133,7 @@ __device__ __forceinline__ void agc_chain_pipe(float *grp, float *stw0, size_t s
 #endif
   // (rolled loops: one copy of the four-step block -- ~1300 instructions -- instead of sixteen; the register ring
   // of requested chunks rotates by moves.  Measured: the inner loop unrolled, four copies, runs 12 % faster per step
-  // and the kernel 6 % slower (two copies: 1.5 % slower) -- the other waves' front and back ends share the instruction cache; six chunks ahead
-  // instead of four spill: 23 % slower)
+  // and the kernel 6 % slower (two copies: 1.5 % slower) -- the other waves' front and back ends share the instruction cache)
 #pragma nounroll
   for (int k = 0; k < 256 / kPipeChunk; ++k) {
     {

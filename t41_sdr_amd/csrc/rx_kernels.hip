@@ -967,21 +967,23 @@ __device__ __forceinline__ void agc_apply(const cf (&v)[8], float4 agst, float *
 // frame g - 1, instead of between two workgroup barriers.
 //   * Geometry of the AGC-off kernel: one resident 16-wave workgroup per CU, one channel per wave,
 //     filter memories on chip for the whole launch.
-//   * The chain of frame g is run by ONE wave (g mod the workgroup's channel count: the duty
-//     rotates) for all the workgroup's channels, one lane per channel, 16 channels' worth of
-//     instruction issue for the price of one.  Its inputs (look-ahead maxima, |popped sample|) and
+//   * The chain of frame g is run by ONE wave -- the first that gets to its duty point for g (a
+//     compare-and-swap on the next unclaimed frame): the one furthest ahead, which is sure to be
+//     waiting when the previous chain ends and can best afford to fall a chain behind -- for all
+//     the workgroup's channels, one lane per channel, 16 channels' worth of instruction issue for
+//     the price of one.  Its inputs (look-ahead maxima, |popped sample|) and
 //     outputs (volts) and the popped samples the gain is applied to travel through a per-channel
 //     ring of three slots in global memory (RxArgs::agc_pipe; the slices have no LDS left, and
 //     the AGC's delay line rides in four registers): a wave's program per iteration f is
 //         front end + AGC preparation of frame f     -> slot f mod 3, ready[f mod 3] += 1
-//         (duty wave of frame f - 1) chain of f - 1  -> waits for ready == channels and done == f - 1
+//         (if it takes the duty for f - 1) chain of f - 1 -> waits for ready == channels and done == f - 1
 //         gain + demodulator + back end of f - 2     -> waits for done > f - 2 (its loads are
 //                                                       requested ahead of the preparation when the
 //                                                       chain is done by then, which is the rule)
 //     The back end trails by TWO frames: the wave that ran a chain is one chain (~60 k cycles)
 //     behind the others from then on, and the next chain needs ITS channel's inputs too -- with a
 //     single frame of slack that lag would sit on the chain's critical path every frame.
-//   * Flags: four words of LDS behind the FFT twiddles; waits are bounded spins (a logic error
+//   * Flags: five words of LDS behind the FFT twiddles; waits are bounded spins (a logic error
 //     then shows as wrong samples in the parity tests, not as a hung GPU).  Release / acquire at
 //     workgroup scope: the waves of a workgroup share the CU's vector memory path and L1, which
 //     keeps their global accesses in order, so the fences cost an LDS wait and no vmcnt(0).
@@ -998,7 +1000,10 @@ __device__ __forceinline__ void agc_apply(const cf (&v)[8], float4 agst, float *
 // the AGC-off kernel's 1767 at the same 62 % VALU utilisation: every phase is stretched, the chain included).
 // ------------------------------------------------------------------------------------------
 constexpr int kPipeSlots = 3, kPipeSlotFloats = 1024;  // ring_max -> volts [256] | |popped| [256] | popped re [256] | popped im [256] (AM only)
-constexpr int kPipeFlags = 1008;                        // float index in the table area: ready[3], done
+constexpr int kPipeFlags = 1008;                        // float index in the table area: ready[3], done, next frame to claim
+#ifndef T41RX_PIPE_CLAIM
+#define T41RX_PIPE_CLAIM 1  // 0: the duty rotates (frame g -> wave g mod channels); measured 1.2 % slower
+#endif
 constexpr int kPipeSpinCap = 1 << 20;
 
 // -DT41RX_PIPE_STAT (diagnostic build, tools/build_variant.sh pstat -DT41RX_PIPE_STAT; T41RX_PIPE_STAT=1 prints them when
@@ -2371,7 +2376,24 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
 #endif
         }
         const int g = f - 1;  // the frame whose chain is due
+#if T41RX_PIPE_CLAIM
+        // the duty goes to the first wave that gets here (the one furthest ahead: it is sure to be waiting when the previous
+        // chain ends, and it can best afford to fall a chain behind) instead of rotating blindly
+        bool duty = false;
+        if (g >= seg0 && g < seg1) {
+          // flags[4] = the next frame whose chain nobody has taken yet: frame g is taken by the one wave whose
+          // compare-and-swap g -> g + 1 succeeds (a slower wave finds g + 1 or more there, whenever it arrives)
+          unsigned won = 0u;
+          if (lane == 0) {
+            unsigned expect = (unsigned)g;
+            won = __hip_atomic_compare_exchange_strong(flags + 4, &expect, (unsigned)(g + 1), __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1u : 0u;
+          }
+          duty = __builtin_amdgcn_readfirstlane(won) != 0u;
+        }
+        if (duty) {
+#else
         if (g >= seg0 && g < seg1 && g % nvalid == wv) {
+#endif
           {
             PIPE_STAT_T0();
             pipe_wait_ge(flags + g % kPipeSlots, (unsigned)nvalid);

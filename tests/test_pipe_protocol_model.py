@@ -3,8 +3,10 @@ rx512_kernel): 16 waves of one workgroup, each running the program
 
     for f in 0 .. F + 1:
         if f < F:   front end + preparation of frame f  -> writes slot f % 3, ready[f % 3] += 1
-        g = f - 1:  if 0 <= g < F and g % nvalid == wave: wait ready[g % 3] == nvalid, reset it, (request the first
-                    operands,) wait done == g, run the chain of g (reads / writes slot g % 3), done = g + 1
+        g = f - 1:  if 0 <= g < F and this wave takes the duty for g (the first to get here: compare-and-swap on the next
+                    unclaimed frame; or, the other policy modelled, g % nvalid == wave): wait ready[g % 3] == nvalid,
+                    reset it, (request the first operands,) wait done == g, run the chain of g (reads / writes
+                    slot g % 3), done = g + 1
         h = f - 2:  if h >= 0: wait done > h, back end of h (reads slot h % 3)
 
 with arbitrary (random) durations of every phase.  Checked on many random schedules: it terminates (no wave waits for
@@ -17,9 +19,10 @@ import random
 import pytest
 
 
-def simulate(nvalid, F, rng, chain_cost, front_cost, back_cost):
+def simulate(nvalid, F, rng, chain_cost, front_cost, back_cost, claim=False):
     ready = [0, 0, 0]
     done = 0
+    next_claim = [0]  # claim=True: the chain of frame g goes to the first wave that gets to its duty point (compare-and-swap g -> g + 1)
     t_prep_end = [[None] * F for _ in range(nvalid)]       # [wave][frame]
     t_back = [[(None, None)] * F for _ in range(nvalid)]   # (start, end)
     t_chain = [(None, None)] * F
@@ -31,7 +34,13 @@ def simulate(nvalid, F, rng, chain_cost, front_cost, back_cost):
                 yield ("run", front_cost())
                 yield ("prep_done", f)
             g = f - 1
-            if 0 <= g < F and g % nvalid == w:
+            mine = 0 <= g < F and g % nvalid == w
+            if claim and 0 <= g < F:
+                assert next_claim[0] >= g, "a wave reaches frame g's duty point before g - 1 was taken"
+                mine = next_claim[0] == g
+                if mine:
+                    next_claim[0] = g + 1
+            if mine:
                 yield ("wait_ready", g)
                 yield ("wait_done_eq", g)
                 yield ("chain_begin", g)
@@ -130,8 +139,9 @@ def simulate(nvalid, F, rng, chain_cost, front_cost, back_cost):
     return max(now)
 
 
+@pytest.mark.parametrize("claim", [False, True], ids=["rotating-duty", "claimed-duty"])
 @pytest.mark.parametrize("nvalid", [1, 2, 3, 5, 16])
-def test_protocol_terminates_and_orders_every_access(nvalid):
+def test_protocol_terminates_and_orders_every_access(nvalid, claim):
     rng = random.Random(1000 + nvalid)
     for trial in range(60):
         F = rng.choice([4, 5, 7, 16, 33])
@@ -144,7 +154,7 @@ def test_protocol_terminates_and_orders_every_access(nvalid):
             costs = (lambda: rng.uniform(0.1, 1), lambda: rng.choice([1, 5, 300]), lambda: rng.choice([1, 100]))
         else:             # everything random over three decades
             costs = (lambda: 10 ** rng.uniform(-1, 2), lambda: 10 ** rng.uniform(-1, 2), lambda: 10 ** rng.uniform(-1, 2))
-        simulate(nvalid, F, rng, *costs)
+        simulate(nvalid, F, rng, *costs, claim=claim)
 
 
 def test_two_frames_of_slack_keep_the_duty_waves_lag_off_the_chain_path():

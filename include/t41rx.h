@@ -176,9 +176,12 @@ int t41rx_process_host_q15(t41rx_ctx *ctx, const int16_t *Q_in_L, const int16_t 
  * The buffer starts with a 32-byte header (magic, abi, fft_length, n_channels, floats per channel,
  * 3 reserved); t41rx_set_state() refuses (T41RX_ERR_STATE) a checkpoint of another ABI, FFT length
  * or channel count, and one whose AGC state words, oscillator amplitude or synchronous-detector PLL
- * words (phase in [0, 2 pi), frequency within +-pll_fmax) are out of range.  The checkpoint is the
+ * words (phase in [0, 2 pi], frequency within +-pll_fmax) are out of range.  The checkpoint is the
  * path's streaming state; the memories of the optional side stages -- the display FFT's zoom filters
- * and ring, the noise-reduction / notch state -- are not in it. */
+ * and ring, the noise-reduction / notch state -- are not in it.
+ * t41rx_get_state() also returns T41RX_ERR_STATE if a wait inside the pipelined AGC / SAM kernels has run out since
+ * the last t41rx_reset() (their waits are bounded so that a broken hand-over cannot hang the GPU; it cannot happen
+ * unless the kernel is wrong, and then the samples are not to be trusted). */
 size_t t41rx_state_bytes(const t41rx_ctx *ctx);
 int    t41rx_get_state(t41rx_ctx *ctx, void *host_buf, size_t bytes);
 int    t41rx_set_state(t41rx_ctx *ctx, const void *host_buf, size_t bytes);

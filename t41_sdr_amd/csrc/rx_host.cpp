@@ -498,6 +498,9 @@ int t41rx_reset(t41rx_ctx *ctx) {
   if (!ctx) return fail(T41RX_ERR_ARG, "null argument");
   DeviceGuard g(ctx->device);
   HIP_TRY(hipDeviceSynchronize());
+  if (ctx->d_agc_pipe)  // (and the pipelined kernels' time-out counter, see pipe_timeouts)
+    HIP_TRY(hipMemset(reinterpret_cast<char *>(ctx->d_agc_pipe) + (size_t)ctx->nchan * 3 * 1024 * sizeof(float) +
+                          ((size_t)ctx->nchan + 15) * 16 * sizeof(unsigned long long), 0, sizeof(unsigned long long)));
   return reset_state(ctx);
 }
 
@@ -730,11 +733,23 @@ size_t t41rx_state_bytes(const t41rx_ctx *ctx) {
   return kStateHeaderBytes + sizeof(float) * state_floats(ctx->params.fft_length) * (size_t)ctx->nchan;
 }
 
+// the pipelined kernels count a wait that ran out (rx_kernels.hip: pipe_wait_ge) behind their slots: a broken hand-over
+// protocol would leave wrong samples, not a hung GPU -- reported at the calls that synchronise anyway
+static int pipe_timeouts(t41rx_ctx *ctx) {
+  if (!ctx->d_agc_pipe) return 0;
+  unsigned n = 0;
+  const char *p = reinterpret_cast<const char *>(ctx->d_agc_pipe) + (size_t)ctx->nchan * 3 * 1024 * sizeof(float) +
+                  ((size_t)ctx->nchan + 15) * 16 * sizeof(unsigned long long);
+  if (hipMemcpy(&n, p, sizeof(n), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return (int)n;
+}
+
 int t41rx_get_state(t41rx_ctx *ctx, void *host_buf, size_t bytes) {
   if (!ctx || !host_buf) return fail(T41RX_ERR_ARG, "null argument");
   if (bytes < t41rx_state_bytes(ctx)) return fail(T41RX_ERR_STATE, "state buffer too small");
   DeviceGuard g(ctx->device);
   HIP_TRY(hipDeviceSynchronize());
+  if (pipe_timeouts(ctx) != 0) return fail(T41RX_ERR_STATE, "a wait inside the pipelined AGC / SAM kernel ran out: the samples since the last checkpoint are not valid");
   int32_t hdr[8] = {(int32_t)kStateMagic, T41RX_ABI_VERSION, ctx->params.fft_length, ctx->nchan,
                     (int32_t)state_floats(ctx->params.fft_length), 0, 0, 0};
   std::memcpy(host_buf, hdr, sizeof(hdr));

@@ -1004,7 +1004,10 @@ constexpr int kPipeFlags = 1008;                        // float index in the ta
 #ifndef T41RX_PIPE_CLAIM
 #define T41RX_PIPE_CLAIM 1  // 0: the duty rotates (frame g -> wave g mod channels); measured 1.2 % slower
 #endif
-constexpr int kPipeSpinCap = 1 << 20;
+#ifndef T41RX_PIPE_SPINCAP
+#define T41RX_PIPE_SPINCAP (1 << 20)  // (tools: a build with 1 exercises the time-out report)
+#endif
+constexpr int kPipeSpinCap = T41RX_PIPE_SPINCAP;
 
 // -DT41RX_PIPE_STAT (diagnostic build, tools/build_variant.sh pstat -DT41RX_PIPE_STAT; T41RX_PIPE_STAT=1 prints them when
 // the context is destroyed): 16 cycle counters per wave behind the slots -- [0] chain [1] chains [2] slow blocks [3] waiting
@@ -1022,11 +1025,15 @@ constexpr int kPipeSpinCap = 1 << 20;
 __device__ __forceinline__ unsigned pipe_flag_read(const unsigned *p) {
   return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
 }
-__device__ __forceinline__ void pipe_wait_ge(const unsigned *p, unsigned target) {
-  for (int it = 0; it < kPipeSpinCap; ++it) {
+// (err: a counter behind the slots.  A wait that runs out -- it cannot, unless the protocol is broken -- is counted
+// there and the wave goes on: the host reports it at the next synchronising call, rx_host.cpp, instead of a hung GPU)
+__device__ __forceinline__ void pipe_wait_ge(const unsigned *p, unsigned target, unsigned *err) {
+  int it = 0;
+  for (; it < kPipeSpinCap; ++it) {
     if (pipe_flag_read(p) >= target) break;
     __builtin_amdgcn_s_sleep(2);
   }
+  if (it == kPipeSpinCap && (threadIdx.x & 63) == 0) atomicAdd(err, 1u);
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
@@ -1092,7 +1099,7 @@ constexpr int kPipeStageFloats = 16 * kPipeChStride;
 #define T41RX_PIPE_AHEAD 2  // chunks requested ahead (measured: 1, 2, 3, 4 within 1 %; 6 spills and is 23 % slower)
 #endif
 __device__ __forceinline__ void agc_chain_pipe(float *grp, float *stw0, size_t stride, float *stage, const unsigned *done, unsigned g,
-                                               int nvalid, CoefPtr cf0, int lane, unsigned long long *pipe_stat) {
+                                               int nvalid, CoefPtr cf0, int lane, unsigned long long *pipe_stat, unsigned *err) {
   const CoefPtr c = fresh_coef(cf0);
   AgcConsts gc;
   gc.attack_mult = c->agc[kAgcAttackMult];
@@ -1120,7 +1127,7 @@ __device__ __forceinline__ void agc_chain_pipe(float *grp, float *stw0, size_t s
   }
   {
     PIPE_STAT_T0();
-    pipe_wait_ge(done, g);  // the previous frame's chain has left the state words
+    pipe_wait_ge(done, g, err);  // the previous frame's chain has left the state words
     PIPE_STAT_ADD(4);
   }
   PIPE_STAT_T0();
@@ -1262,7 +1269,7 @@ __device__ __forceinline__ void sam_prep_pipe(const cf (&v)[8], float fixed_gain
 }
 //   grp : slot (frame g) of the workgroup's first channel; ms0 : its kStMisc words, channel c's stride floats further
 __device__ __forceinline__ void sam_chain_pipe(float *grp, float *ms0, size_t stride, float *stage, const float *tab, const unsigned *done,
-                                               unsigned g, int nvalid, CoefPtr cf0, int lane) {
+                                               unsigned g, int nvalid, CoefPtr cf0, int lane, unsigned *err) {
   const int ch = (nvalid == 16) ? (lane & 15) : (lane & 15) % nvalid;
   const int q = lane >> 4;
   float *gsrc = grp + (size_t)ch * (kPipeSlots * kPipeSlotFloats);
@@ -1276,7 +1283,7 @@ __device__ __forceinline__ void sam_chain_pipe(float *grp, float *ms0, size_t st
   }
   wave_sync();
   for (int i = lane; i < 516; i += 64) stage[i] = tab[i];
-  pipe_wait_ge(done, g);  // the previous frame's loop has left the PLL words
+  pipe_wait_ge(done, g, err);  // the previous frame's loop has left the PLL words
   wave_sync();
   float *ms = ms0 + (size_t)ch * stride;
   SamPll pll;
@@ -2343,6 +2350,8 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
         constexpr bool NEED_IM = (MODE == kModeAm);
         unsigned long long *pipe_stat = reinterpret_cast<unsigned long long *>(a.agc_pipe + (size_t)a.nchan * kPipeSlots * kPipeSlotFloats) + (size_t)job * 16;
         (void)pipe_stat;
+        unsigned *pipe_err = reinterpret_cast<unsigned *>(reinterpret_cast<unsigned long long *>(a.agc_pipe + (size_t)a.nchan * kPipeSlots * kPipeSlotFloats) +
+                                                          ((size_t)a.nchan + 15) * 16);
 #ifdef T41RX_PIPE_STAT
         if (f < seg1 && lane == 0) {
           const unsigned long long now = __builtin_readcyclecounter();
@@ -2396,7 +2405,7 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
 #endif
           {
             PIPE_STAT_T0();
-            pipe_wait_ge(flags + g % kPipeSlots, (unsigned)nvalid);
+            pipe_wait_ge(flags + g % kPipeSlots, (unsigned)nvalid, pipe_err);
             PIPE_STAT_ADD(4);
           }
           if (lane == 0) __hip_atomic_store(flags + g % kPipeSlots, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -2406,10 +2415,10 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
                         "chain staging: 16 channels, inside the X scratch");
           if (PSAM)
             sam_chain_pipe(a.agc_pipe + (ch0 * kPipeSlots + g % kPipeSlots) * kPipeSlotFloats, a.state + ch0 * state_stride + kStMisc, state_stride,
-                           lds + kScr, reinterpret_cast<const float *>(a.tab + kTabSam), flags + 3, (unsigned)g, nvalid, cf0, lane);
+                           lds + kScr, reinterpret_cast<const float *>(a.tab + kTabSam), flags + 3, (unsigned)g, nvalid, cf0, lane, pipe_err);
           else
             agc_chain_pipe(a.agc_pipe + (ch0 * kPipeSlots + g % kPipeSlots) * kPipeSlotFloats, a.state + ch0 * state_stride + st_agc(512) + kAgcHistFloats,
-                           state_stride, lds + kScr, flags + 3, (unsigned)g, nvalid, cf0, lane, pipe_stat);
+                           state_stride, lds + kScr, flags + 3, (unsigned)g, nvalid, cf0, lane, pipe_stat, pipe_err);
           PRIO(1);
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
           if (lane == 0) __hip_atomic_store(flags + 3, (unsigned)(g + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -2417,7 +2426,7 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
         if (f < seg0 + kSkew) continue;  // nothing to finish yet
         if (!early) {
           PIPE_STAT_T0();
-          pipe_wait_ge(flags + 3, (unsigned)(fb + 1));
+          pipe_wait_ge(flags + 3, (unsigned)(fb + 1), pipe_err);
           PIPE_STAT_ADD(3);
           if (PSAM) gin.vv = *reinterpret_cast<const float4 *>(bslot + 512 + 4 * lane);
           else gin = agc_gain_request<NEED_IM>(bslot, lane);

@@ -61,6 +61,9 @@ namespace t41 {
 // Fused kernel: how many of the next frame's sub-blocks are requested during the current frame
 // (0: none, 1: sub-block 0 + the I tail, 2: sub-blocks 0 and 1 + the I tail).  Each one costs 16
 // registers that stay live through the back end.
+#ifndef T41RX_PIPE_PF
+#define T41RX_PIPE_PF 1  // (2: 2.4 % slower -- 212 instead of 108 bytes of scratch per lane, spilled and reloaded every frame; 0: the same as 1)
+#endif
 #ifndef T41RX_PF
 #define T41RX_PF 2
 #endif
@@ -1402,6 +1405,9 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
   static_assert(!PIPE || ((AGC != (MODE == kModeSam)) && PART == 0 && !DEBUG && !SEGPAR && T41RX_RESIDENT),
                 "PIPE: the pipelined variants -- AGC on (see agc_prep_pipe), or the synchronous detector with the AGC off (sam_chain_pipe)");
   constexpr bool PSAM = PIPE && MODE == kModeSam;
+  // input sub-blocks of the NEXT frame requested across the back end (the pipelined kernels hold them across the
+  // preparation, a chain and the back end of an older frame: registers that spill there)
+  constexpr int kPF = PIPE ? T41RX_PIPE_PF : T41RX_PF;
   typedef Geo<PART, geo4(MODE, AGC) && !PIPE> G;
   constexpr bool KEEP = G::kResident;  // streaming state stays on chip across the frames of a launch
   constexpr int NW = G::kWaves;
@@ -1627,8 +1633,8 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
       // requested while the current frame's last two sub-blocks are processed and arrive under its
       // back end, so a wave does not sit out a memory round trip at every frame start.
       const bool hist_carried = (PART == 1 || KEEP) && !first_iter;
-      const bool carried = (PART == 1 || (KEEP && T41RX_PF >= 1)) && !first_iter;   // sub-block 0 (and the tail)
-      const bool carried1 = (PART == 1 || (KEEP && T41RX_PF >= 2)) && !first_iter;  // sub-block 1
+      const bool carried = (PART == 1 || (KEEP && kPF >= 1)) && !first_iter;   // sub-block 0 (and the tail)
+      const bool carried1 = (PART == 1 || (KEEP && kPF >= 2)) && !first_iter;  // sub-block 1
       const bool preroll = SEGPAR && first_iter && f > 0;  // this wave rebuilds its filter memories from the preceding input
       if (preroll) {  // requested first, into register set 1 (sub-block 1 is requested once the pre-roll is done)
         if (!WQ15) {
@@ -1885,7 +1891,7 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
               pI0[h] = ldg_stream(gI + o);
               pQ0[h] = ldg_stream(gQ + o);
             }
-          } else if (PART == 1 || (KEEP && T41RX_PF >= 1)) {  // the next segment's / frame's sub-blocks 0 and 1 (same channel: contiguous)
+          } else if (PART == 1 || (KEEP && kPF >= 1)) {  // the next segment's / frame's sub-blocks 0 and 1 (same channel: contiguous)
             if (f + 1 < seg1) {
               if (KEEP && s == 3) {  // and the I tail that decides the next frame's Q start state
                 if (!WQ15) {
@@ -1894,7 +1900,7 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
                   tailNq = *reinterpret_cast<const float2 *>(gI + L / 2 + (L - 256) / 2 + 2 * lane);
                 }
               }
-              if (KEEP && T41RX_PF < 2 && s == 3) {
+              if (KEEP && kPF < 2 && s == 3) {
                 // sub-block 1 is requested at the top of the next frame
               } else if (!WQ15) {
                 const int o = L + 512 * (s - 2) + 8 * lane;

@@ -62,6 +62,9 @@ WORKLOADS = {
     "ssb_q15": dict(batch=4096, fft=512, kw=dict(mode=0, FLoCut=200, FHiCut=3000), q15=True,
                     name="configs[1] on the firmware's own sample format either side (q15 record-queue blocks in, "
                          "arm_float_to_q15 out; Process.cpp:102-111, 936): 6 B per input complex sample (SURVEY 8f rank 3)"),
+    "ssb_agc_q15": dict(batch=4096, fft=512, kw=dict(mode=0, FLoCut=200, FHiCut=3000, AGCMode=1), q15=True,
+                        name="configs[1] exactly as the firmware ships: AGCMode = 1 (gwv.cpp:15) and q15 samples either side "
+                             "(Process.cpp:102-111, 936): 6 B per input complex sample"),
     "ssb_notch": dict(batch=4096, fft=512, kw=dict(mode=0, FLoCut=200, FHiCut=3000, ANR_notchOn=1), frames=8,
                       name="configs[1] with the automatic notch on (Xanr(), Noise.cpp:322-370, Process.cpp:862-866; SURVEY 8f rank 4): "
                            "fused kernel up to the demodulator, lane-per-channel LMS kernel, interpolator kernel"),

@@ -35,37 +35,55 @@ namespace t41 {
 // ------------------------------------------------------------------------------------------
 constexpr int kAnrRow = 65;                    // LDS row pitch in floats (64 channels + 1)
 constexpr int kAnrTile = kAnrHist + 256;       // rows of the input tile: 79 of history + the frame
-constexpr size_t kAnrLdsBytes = (size_t)(kAnrTile + 256) * kAnrRow * sizeof(float);  // input tile + output tile
+constexpr size_t kAnrLdsBytes = ((size_t)(kAnrTile + 256) * kAnrRow + 3 + 512) * sizeof(float);  // input tile + output tile + two slots of 64 x (sigma, 1 / sigma', 1 - 2 mu sigma / sigma' as a double)
 
-// One pass of Noise.cpp:331-369 over the 256 samples in T[kAnrHist ..] for this lane's channel.
-// out (may be null): O tile.
+// One pass of Noise.cpp:331-369 over the 256 samples in T[kAnrHist ..], split over the workgroup's TWO waves (lane =
+// channel in both): a sample's step is ~430 instructions for one wave, most of them the two sums over the 64-tap
+// window, each a dependent chain in tap order.  Wave 1 takes the window's sum of squares (ANR_sigma), wave 0 the
+// filter output, the error, the leak logic and the taps' update; sigma crosses through LDS (two slots: wave 1 may
+// be a sample ahead) behind ONE workgroup barrier per sample.  Every value by the same operations in the same order
+// as the scalar loop.
+// O (may be null): output tile; SIG: [2][64] float4.
 template <bool NOTCH>
-__device__ __forceinline__ void anr_pass(const float *T, float *O, f2 (&w)[kAnrTaps / 2], float &lidx, float &ngamma, int lane) {
+__device__ __forceinline__ void anr_pass_y(const float *T, float *O, const float *SIG, f2 (&w)[kAnrTaps / 2], float &lidx, float &ngamma, int lane) {
 #pragma clang fp contract(off)
   const float ANR_den_mult = 6.25e-10, ANR_gamma = 0.1, ANR_lidx_min = 120.0, ANR_lidx_max = 200.0;
   const float ANR_lincr = 1.0, ANR_ldecr = 3.0, ANR_two_mu = 0.0001;
-  for (int i = 0; i < 256; ++i) {
+  // The taps' update of sample i (96 independent instructions) is fused, pair by pair, into the dot product of sample
+  // i + 1 (a chain of 64 dependent additions whose latency it fills): tap pair j is updated, then used.  Same values
+  // as updating all taps first.  Two window register sets alternate (the loop is unrolled by two).
+  float c0 = 1.0f, c1 = 0.0f;  // pending update of the previous sample (none yet: w * 1 + 0 * d would not be exact for
+  bool pending = false;        // -0 / NaN taps, so it is skipped rather than applied)
+  // Two window register sets alternate (the loop is unrolled by two): dj receives this sample's window -- all of it
+  // requested BEFORE the chain starts, one LDS round trip exposed per sample instead of one per pair (measured:
+  // 258 -> 214 us per frame; requesting the next sample's window a step ahead instead is slower: more than 15 LDS reads
+  // in flight make the wait for sigma wait for them too) --, dp still holds the previous sample's for the fused update.
+  auto step = [&](int i, f2 (&dj)[kAnrTaps / 2], const f2 (&dp)[kAnrTaps / 2]) {
     const float *row = T + i * kAnrRow + lane;
     const float d_in = row[kAnrHist * kAnrRow];  // ANR_d[ANR_in_idx]
-    // (two taps per multiply instruction -- v_pk_mul_f32 rounds each product exactly like the scalar multiply -- and the
-    // sums accumulated one product at a time in tap order: the reference's roundings, fewer instructions)
     // A register pair holds taps (j + 1, j) in (.x, .y): the window's rows ascend in time, i.e. descend in j, so one
     // ds_read2_b32 fills a pair without a move.
-    f2 dj[kAnrTaps / 2];
-    float y = 0, sigma = 0;
 #pragma unroll
-    for (int j = 0; j < kAnrTaps; j += 2) {  // idx = in_idx + j + ANR_delay: the sample written j + 16 steps ago
+    for (int j = 0; j < kAnrTaps; j += 2)  // idx = in_idx + j + ANR_delay: the sample written j + 16 steps ago
       dj[j / 2] = f2{row[(kAnrTaps - 2 - j) * kAnrRow], row[(kAnrTaps - 1 - j) * kAnrRow]};
-      const f2 p = w[j / 2] * dj[j / 2], q = dj[j / 2] * dj[j / 2];
+    __builtin_amdgcn_sched_barrier(0);
+    // (two taps per multiply instruction -- v_pk_mul_f32 rounds each product exactly like the scalar multiply -- and the
+    // sum accumulated one product at a time in tap order: the reference's roundings, fewer instructions)
+    float y = 0;
+#pragma unroll
+    for (int j = 0; j < kAnrTaps; j += 2) {
+      if (pending) w[j / 2] = splat(c0) * w[j / 2] + splat(c1) * dp[j / 2];
+      const f2 p = w[j / 2] * dj[j / 2];
       y += p.y;
-      sigma += q.y;
       y += p.x;
-      sigma += q.x;
     }
-    const float inv_sigp = (float)(1.0 / ((double)sigma + 1e-10));
+    __syncthreads();  // wave 1's sigma of this sample is in its slot, with what depends on sigma alone (an IEEE double division)
+    const float4 sg = *reinterpret_cast<const float4 *>(SIG + 4 * (64 * (i & 1) + lane));
+    const float sigma = sg.x, inv_sigp = sg.y;  // inv_sigp = (float)(1.0 / ((double)sigma + 1e-10))
+    const double one_m = __hiloint2double(__float_as_int(sg.w), __float_as_int(sg.z));  // 1.0 - (double)(ANR_two_mu * sigma * inv_sigp)
     const float error = d_in - y;
     if (O) O[i * kAnrRow + lane] = NOTCH ? error : y;
-    float nel = (float)((double)error * (1.0 - (double)(ANR_two_mu * sigma * inv_sigp)));
+    float nel = (float)((double)error * one_m);
     if (nel < 0.0f) nel = -nel;
     float nev = (float)((double)d_in - (1.0 - (double)(ANR_two_mu * ngamma)) * (double)y - (double)(ANR_two_mu * error * sigma * inv_sigp));
     if (nev < 0.0f) nev = -nev;
@@ -79,61 +97,105 @@ __device__ __forceinline__ void anr_pass(const float *T, float *O, f2 (&w)[kAnrT
       }
     }
     ngamma = ANR_gamma * (lidx * lidx) * (lidx * lidx) * ANR_den_mult;
-    const float c0 = (float)(1.0 - (double)(ANR_two_mu * ngamma));
-    const float c1 = ANR_two_mu * error * inv_sigp;
+    c0 = (float)(1.0 - (double)(ANR_two_mu * ngamma));
+    c1 = ANR_two_mu * error * inv_sigp;
+    pending = true;
+  };
+  f2 da[kAnrTaps / 2], db[kAnrTaps / 2];
 #pragma unroll
-    for (int j = 0; j < kAnrTaps / 2; ++j) w[j] = splat(c0) * w[j] + splat(c1) * dj[j];
+  for (int j = 0; j < kAnrTaps / 2; ++j) db[j] = splat(0.0f);
+  for (int i = 0; i < 256; i += 2) {
+    step(i, da, db);
+    step(i + 1, db, da);
+  }
+  // the last sample's update (its window is in db)
+#pragma unroll
+  for (int j = 0; j < kAnrTaps / 2; ++j) w[j] = splat(c0) * w[j] + splat(c1) * db[j];
+}
+__device__ __forceinline__ void anr_pass_sigma(const float *T, float *SIG, int lane) {
+#pragma clang fp contract(off)
+  for (int i = 0; i < 256; ++i) {
+    const float *row = T + i * kAnrRow + lane;
+    float sigma = 0;
+#pragma unroll
+    for (int j = 0; j < kAnrTaps; j += 2) {
+      const f2 d = f2{row[(kAnrTaps - 2 - j) * kAnrRow], row[(kAnrTaps - 1 - j) * kAnrRow]};
+      const f2 q = d * d;
+      sigma += q.y;
+      sigma += q.x;
+    }
+    const float ANR_two_mu = 0.0001;
+    const float inv_sigp = (float)(1.0 / ((double)sigma + 1e-10));
+    const double one_m = 1.0 - (double)(ANR_two_mu * sigma * inv_sigp);
+    *reinterpret_cast<float4 *>(SIG + 4 * (64 * (i & 1) + lane)) =
+        make_float4(sigma, inv_sigp, __int_as_float(__double2loint(one_m)), __int_as_float(__double2hiint(one_m)));
+    __syncthreads();
   }
 }
 
-__global__ __launch_bounds__(64, 1) void anr_kernel(const NrArgs a) {
+__global__ __launch_bounds__(128, 1) void anr_kernel(const NrArgs a) {
 #pragma clang fp contract(off)
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float *T = sm, *O = sm + kAnrTile * kAnrRow;
-  const int lane = threadIdx.x;
+  float *T = sm, *O = sm + kAnrTile * kAnrRow, *SIG = sm + (((kAnrTile + 256) * kAnrRow + 3) & ~3);  // (16-byte aligned)
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // 0: filter output and update, 1: sum of squares
   const int ch0 = blockIdx.x * 64;
   const int nlive = (a.nchan - ch0 < 64) ? a.nchan - ch0 : 64;
   const int ch = ch0 + (lane < nlive ? lane : nlive - 1);  // dead lanes shadow the last live channel (their stores are skipped)
   const size_t nch = (size_t)a.nchan;
-  f2 w[kAnrTaps / 2];  // ANR_w, two taps per register pair: (.x, .y) = taps (2 j + 1, 2 j), see anr_pass
+  f2 w[kAnrTaps / 2];  // ANR_w (wave 0), two taps per register pair: (.x, .y) = taps (2 j + 1, 2 j), see anr_pass_y
+  float lidx = 0, ngamma = 0;
+  if (wv == 0) {
 #pragma unroll
-  for (int j = 0; j < kAnrTaps / 2; ++j) w[j] = f2{a.anr[(size_t)(kAnrStW + 2 * j + 1) * nch + ch], a.anr[(size_t)(kAnrStW + 2 * j) * nch + ch]};
-  for (int r = 0; r < kAnrHist; ++r) T[r * kAnrRow + lane] = a.anr[(size_t)(kAnrStHist + r) * nch + ch];
-  float lidx = a.anr[(size_t)kAnrStLidx * nch + ch], ngamma = a.anr[(size_t)kAnrStNgamma * nch + ch];
+    for (int j = 0; j < kAnrTaps / 2; ++j) w[j] = f2{a.anr[(size_t)(kAnrStW + 2 * j + 1) * nch + ch], a.anr[(size_t)(kAnrStW + 2 * j) * nch + ch]};
+    for (int r = 0; r < kAnrHist; ++r) T[r * kAnrRow + lane] = a.anr[(size_t)(kAnrStHist + r) * nch + ch];
+    lidx = a.anr[(size_t)kAnrStLidx * nch + ch], ngamma = a.anr[(size_t)kAnrStNgamma * nch + ch];
+  }
   for (int f = 0; f < a.nframes; ++f) {
-    // stage the frame in: row c of the scratch = channel ch0 + c, 256 consecutive samples, 4 x 256 B per row
+    // stage the frame in: row c of the scratch = channel ch0 + c, 256 consecutive samples, 4 x 256 B per row (the two
+    // waves take alternate channels)
     __syncthreads();
-    for (int c = 0; c < nlive; ++c) {
+    for (int c = wv; c < nlive; c += 2) {
       const float *src = a.aud + ((size_t)(ch0 + c) * a.nframes + f) * 256;
 #pragma unroll
       for (int q = 0; q < 4; ++q) T[(kAnrHist + lane + 64 * q) * kAnrRow + c] = src[lane + 64 * q];
     }
-    for (int c = nlive; c < 64; ++c) {
+    for (int c = nlive + ((nlive ^ wv) & 1); c < 64; c += 2) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) T[(kAnrHist + lane + 64 * q) * kAnrRow + c] = 0.0f;
     }
     __syncthreads();
     if (a.nr_option == 3) {  // Process.cpp:852-857: Xanr() as noise reduction; its result stays in float_buffer_R, float_buffer_L is scaled by 1.5
-      anr_pass<false>(T, nullptr, w, lidx, ngamma, lane);
-      if (a.notch) {
-        // the notch pass sees the scaled block behind the unscaled one: its delay line = the last 79 unscaled samples
-        for (int r = 0; r < kAnrHist; ++r) T[r * kAnrRow + lane] = T[(256 + r) * kAnrRow + lane];
-        for (int i = 0; i < 256; ++i) T[(kAnrHist + i) * kAnrRow + lane] = T[(kAnrHist + i) * kAnrRow + lane] * 1.5f;
-      } else {
-        for (int i = 0; i < 256; ++i) O[i * kAnrRow + lane] = T[(kAnrHist + i) * kAnrRow + lane] * 1.5f;
+      if (wv == 0) anr_pass_y<false>(T, nullptr, SIG, w, lidx, ngamma, lane);
+      else anr_pass_sigma(T, SIG, lane);
+      __syncthreads();
+      if (wv == 0) {
+        if (a.notch) {
+          // the notch pass sees the scaled block behind the unscaled one: its delay line = the last 79 unscaled samples
+          for (int r = 0; r < kAnrHist; ++r) T[r * kAnrRow + lane] = T[(256 + r) * kAnrRow + lane];
+          for (int i = 0; i < 256; ++i) T[(kAnrHist + i) * kAnrRow + lane] = T[(kAnrHist + i) * kAnrRow + lane] * 1.5f;
+        } else {
+          for (int i = 0; i < 256; ++i) O[i * kAnrRow + lane] = T[(kAnrHist + i) * kAnrRow + lane] * 1.5f;
+        }
       }
+      __syncthreads();
     }
-    if (a.notch) anr_pass<true>(T, O, w, lidx, ngamma, lane);  // Process.cpp:862-866
+    if (a.notch) {  // Process.cpp:862-866
+      if (wv == 0) anr_pass_y<true>(T, O, SIG, w, lidx, ngamma, lane);
+      else anr_pass_sigma(T, SIG, lane);
+      __syncthreads();
+    }
     // the delay line's live part for the next block
-    for (int r = 0; r < kAnrHist; ++r) T[r * kAnrRow + lane] = T[(256 + r) * kAnrRow + lane];
+    if (wv == 0)
+      for (int r = 0; r < kAnrHist; ++r) T[r * kAnrRow + lane] = T[(256 + r) * kAnrRow + lane];
     __syncthreads();
-    for (int c = 0; c < nlive; ++c) {
+    for (int c = wv; c < nlive; c += 2) {
       float *dst = a.aud + ((size_t)(ch0 + c) * a.nframes + f) * 256;
 #pragma unroll
       for (int q = 0; q < 4; ++q) dst[lane + 64 * q] = O[(lane + 64 * q) * kAnrRow + c];
     }
   }
-  if (lane < nlive) {
+  if (wv == 0 && lane < nlive) {
 #pragma unroll
     for (int j = 0; j < kAnrTaps / 2; ++j) {
       a.anr[(size_t)(kAnrStW + 2 * j + 1) * nch + ch] = w[j].x;
@@ -534,7 +596,7 @@ hipError_t launch_nr(const NrArgs &a, hipStream_t s) {
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&anr_kernel),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAnrLdsBytes);
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL(anr_kernel, dim3((a.nchan + 63) / 64), dim3(64), kAnrLdsBytes, s, a);
+    hipLaunchKernelGGL(anr_kernel, dim3((a.nchan + 63) / 64), dim3(128), kAnrLdsBytes, s, a);
     e = hipGetLastError();
   }
   return e;

@@ -10,7 +10,8 @@
 //  * anr_kernel: Xanr() is a 64-tap adaptive FIR whose every output feeds back into its taps, sample by
 //    sample, and whose sums the reference accumulates in tap order.  ONE LANE PER CHANNEL: a wave runs 64
 //    channels' filters, every lane the reference's loop as written (same operations, same order, no
-//    contraction -- bit-identical to the scalar code), taps in 64 registers, the delay line's live window
+//    contraction -- bit-identical to the scalar code; the step is shared by the TWO waves of the workgroup, see
+//    anr_pass_y), taps in 64 registers, the delay line's live window
 //    in an LDS tile laid out [time][channel] (row pitch 65 floats: conflict-free both for the transposing
 //    stage-in / stage-out and for the per-lane window reads).  The tile is filled and drained with
 //    coalesced row accesses of the [channel][time] scratch.

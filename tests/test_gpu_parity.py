@@ -187,7 +187,7 @@ def test_parity_agc(T, agcmode, mode, nfr, segs):
                          ids=["1ch-usb", "5ch-usb", "17ch-lsb", "21ch-am", "37ch-nfm", "64ch-usb"])
 def test_agc_pipelined_equals_barrier_form(T, nch, mode, agcmode):
     """Calls of four frames or more run the pipelined AGC kernel (rx_kernels.hip: agc_prep_pipe -- the chain of one
-    frame on a rotating duty wave while the others work on the neighbouring frames), shorter ones the barrier form:
+    frame on a duty wave -- the one furthest ahead -- while the others work on the neighbouring frames), shorter ones the barrier form:
     the same samples and the same checkpoint, bit for bit, on ragged batches (last workgroup 5 of 16 channels)"""
     nfr = 14
     nco = siggen.nco_grid(nch, seed=40 + nch)

@@ -62,7 +62,10 @@ namespace t41 {
 // (0: none, 1: sub-block 0 + the I tail, 2: sub-blocks 0 and 1 + the I tail).  Each one costs 16
 // registers that stay live through the back end.
 #ifndef T41RX_PIPE_PF
-#define T41RX_PIPE_PF 1  // (2: 2.4 % slower -- 212 instead of 108 bytes of scratch per lane, spilled and reloaded every frame; 0: the same as 1)
+#define T41RX_PIPE_PF 0  // AGC: 2 is 2.4 % slower (212 bytes of scratch per lane, spilled and reloaded every frame), 1 (108 bytes)
+#endif                   // and 0 (28 bytes) run alike, and 0 moves 1.31 instead of 1.55 x the algorithmic bytes
+#ifndef T41RX_PIPE_PF_SAM
+#define T41RX_PIPE_PF_SAM 1  // (the synchronous detector: 0 is 2 % slower)
 #endif
 #ifndef T41RX_PF
 #define T41RX_PF 2
@@ -1407,7 +1410,7 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
   constexpr bool PSAM = PIPE && MODE == kModeSam;
   // input sub-blocks of the NEXT frame requested across the back end (the pipelined kernels hold them across the
   // preparation, a chain and the back end of an older frame: registers that spill there)
-  constexpr int kPF = PIPE ? T41RX_PIPE_PF : T41RX_PF;
+  constexpr int kPF = PSAM ? T41RX_PIPE_PF_SAM : PIPE ? T41RX_PIPE_PF : T41RX_PF;
   typedef Geo<PART, geo4(MODE, AGC) && !PIPE> G;
   constexpr bool KEEP = G::kResident;  // streaming state stays on chip across the frames of a launch
   constexpr int NW = G::kWaves;

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define T41RX_ABI_VERSION 4
+#define T41RX_ABI_VERSION 5
 
 /* status codes */
 #define T41RX_OK 0
@@ -148,8 +148,25 @@ int t41rx_reset(t41rx_ctx *ctx);
 int t41rx_n_channels(const t41rx_ctx *ctx);
 int t41rx_frame_len(const t41rx_ctx *ctx);
 
+/* How the frames of one process call lie in I / Q / audio (f32 and q15 entry points alike).  The reference has one
+ * channel and one frame per call (float_buffer_L/R[2048], T41_SDR.ino:375-376), so a batch of channels over several
+ * frames has two natural shapes:
+ *   T41RX_LAYOUT_CHANNEL_MAJOR (default)  [n_channels][n_frames * frame_len]: every channel's samples of the call
+ *                                         contiguous in time (one long float_buffer per channel);
+ *   T41RX_LAYOUT_TIME_MAJOR               [n_frames][n_channels][frame_len]: the [n_channels][frame_len] buffers of
+ *                                         n_frames consecutive single-frame calls stacked as they arrive, one batch of
+ *                                         frames every 10.67 ms (ABI 5).
+ * Same arithmetic, same results, same state either way: only the addresses of (channel, frame) differ.  The side
+ * outputs and stage taps keep their documented [n_channels][n_frames][...] shapes.  fft_length 512 only for the
+ * time-major layout (T41RX_ERR_UNSUPPORTED otherwise; a later set_params to a long fft_length is refused likewise). */
+#define T41RX_LAYOUT_CHANNEL_MAJOR 0
+#define T41RX_LAYOUT_TIME_MAJOR 1
+int t41rx_set_buffer_layout(t41rx_ctx *ctx, int layout);
+int t41rx_get_buffer_layout(const t41rx_ctx *ctx);
+
 /* ---- the hot path: ProcessIQData() on every channel ----
- * Device-pointer form: dI, dQ, dAudio are device pointers ([n_channels][n_frames*frame_len]);
+ * Device-pointer form: dI, dQ, dAudio are device pointers ([n_channels][n_frames*frame_len], or time-major:
+ * t41rx_set_buffer_layout);
  * the kernel is enqueued on `hip_stream` (a hipStream_t, may be NULL = default stream) and the
  * call returns without synchronising. */
 int t41rx_process_device(t41rx_ctx *ctx, const float *dI, const float *dQ, float *dAudio,

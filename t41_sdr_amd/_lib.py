@@ -63,6 +63,8 @@ SYMBOLS = {
     "t41rx_reset": (C.c_int, [_vp]),
     "t41rx_n_channels": (C.c_int, [_vp]),
     "t41rx_frame_len": (C.c_int, [_vp]),
+    "t41rx_set_buffer_layout": (C.c_int, [_vp, C.c_int]),
+    "t41rx_get_buffer_layout": (C.c_int, [_vp]),
     "t41rx_process_device": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp]),
     "t41rx_process_host": (C.c_int, [_vp, _fp, _fp, _fp, C.c_int]),
     "t41rx_set_audio_spectrum": (C.c_int, [_vp, _vp, _vp, C.c_int]),

@@ -45,6 +45,7 @@ struct t41rx_ctx {
   float *d_mid = nullptr, *d_aud24 = nullptr;
   float *d_agc_pipe = nullptr;  // AGC on, FFT_LENGTH 512: the pipelined kernel's slots (RxArgs::agc_pipe), allocated on first use
   int scratch_frames = 0;
+  int layout = T41RX_LAYOUT_CHANNEL_MAJOR;  // of I / Q / audio (t41rx_set_buffer_layout)
   int nco_sel = 0;               // long FFT: which NcoState copy is current (flips with every process call)
   // noise reduction / notch (Process.cpp:841-866): state of Xanr() and of the two spectral functions, window tables;
   // allocated when a call first needs them
@@ -504,6 +505,16 @@ int t41rx_reset(t41rx_ctx *ctx) {
   return reset_state(ctx);
 }
 
+int t41rx_set_buffer_layout(t41rx_ctx *ctx, int layout) {
+  if (!ctx) return fail(T41RX_ERR_ARG, "null argument");
+  if (layout != T41RX_LAYOUT_CHANNEL_MAJOR && layout != T41RX_LAYOUT_TIME_MAJOR) return fail(T41RX_ERR_ARG, "unknown buffer layout");
+  if (layout == T41RX_LAYOUT_TIME_MAJOR && ctx->params.fft_length != 512)
+    return fail(T41RX_ERR_UNSUPPORTED, "the time-major layout is built for fft_length 512 (the long-FFT pipeline's kernels walk a channel's samples contiguously)");
+  ctx->layout = layout;
+  return T41RX_OK;
+}
+int t41rx_get_buffer_layout(const t41rx_ctx *ctx) { return ctx ? ctx->layout : T41RX_ERR_ARG; }
+
 int t41rx_n_channels(const t41rx_ctx *ctx) { return ctx ? ctx->nchan : T41RX_ERR_ARG; }
 int t41rx_frame_len(const t41rx_ctx *ctx) { return ctx ? 4 * ctx->params.fft_length : T41RX_ERR_ARG; }
 
@@ -564,6 +575,13 @@ int process_device_impl(t41rx_ctx *ctx, const float *dI, const float *dQ, float 
   a.nco = ctx->d_nco;
   a.nchan = ctx->nchan;
   a.nframes = seg * n_frames;  // 2048-sample segments
+  if (ctx->layout == T41RX_LAYOUT_TIME_MAJOR) {  // [frame][channel][frame_len] (fft_length 512: set_buffer_layout / set_params)
+    a.chan_stride = 2048;
+    a.frame_stride = (long long)ctx->nchan * 2048;
+  } else {
+    a.chan_stride = (long long)a.nframes * 2048;
+    a.frame_stride = 2048;
+  }
   a.seg = seg;
   a.nframes4k = n_frames;
   a.mid = ctx->d_mid;

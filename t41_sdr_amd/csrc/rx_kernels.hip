@@ -57,7 +57,11 @@ namespace t41 {
 #ifndef T41RX_ABLATE
 #define T41RX_ABLATE 0
 #endif
-#define T41RX_CUT(n) (T41RX_ABLATE >= (n) && T41RX_ABLATE <= 8)
+// T41RX_LOO = n (leave one out) cuts exactly stage n of that list and keeps every other one.
+#ifndef T41RX_LOO
+#define T41RX_LOO 0
+#endif
+#define T41RX_CUT(n) ((T41RX_ABLATE >= (n) && T41RX_ABLATE <= 8) || T41RX_LOO == (n))
 // Fused kernel: how many of the next frame's sub-blocks are requested during the current frame
 // (0: none, 1: sub-block 0 + the I tail, 2: sub-blocks 0 and 1 + the I tail).  Each one costs 16
 // registers that stay live through the back end.
@@ -1402,8 +1406,17 @@ static_assert(!Geo<0>::kResident || (Geo<0>::kH1 + 24 <= Geo<0>::kSlice && Geo<0
 // start-up transient); back end = the previous segment's last 28 audio samples.  The channel's
 // state is written by the wave that READ it (the one that starts the call), from the call's last
 // samples in the same way: a wave of a later run may execute before that one has started.
+#ifdef T41RX_CLK
+// Diagnostic build only (-DT41RX_CLK, tools/clock_probe.py): every wave leaves the shader-clock and the constant
+// 100 MHz counter's ticks between its start and its end here (its clock under this load = their ratio x 100 MHz).
+__device__ unsigned long long g_t41_clk[2 * 8192];
+#endif
 template <int MODE, bool DEBUG, int PART, bool PLAIN, bool AGC = false, bool WQ15 = false, bool SEGPAR = false, bool PIPE = false>
 __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64), 4) void rx512_kernel(const RxArgs a) {
+#ifdef T41RX_CLK
+  unsigned long long clk_c0, clk_r0;
+  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk_c0), "=s"(clk_r0)::"memory");
+#endif
   static_assert(!SEGPAR || (PART == 1 && MODE != kModeNfm) || (PART == 2 && MODE == kModeSsb && !AGC), "SEGPAR variants");
   static_assert(!PIPE || ((AGC != (MODE == kModeSam)) && PART == 0 && !DEBUG && !SEGPAR && T41RX_RESIDENT),
                 "PIPE: the pipelined variants -- AGC on (see agc_prep_pipe), or the synchronous detector with the AGC off (sam_chain_pipe)");
@@ -1570,9 +1583,13 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
     if (AGC) PRIO(2); else PRIO(3);  // (AGC on: 3 is the serial chain's, see agc_apply)
     FRESH_LANE();
     const bool first_iter = (f == seg0);
-    const size_t fbase = ((size_t)(T41RX_ABLATE == 9 ? (ch & 15) : ch) * a.nframes + f) * L;
+    // sample offset of (channel, frame) in I / Q / audio: RxArgs::chan_stride / frame_stride (channel-major
+    // [channel][frame][2048]: nframes * 2048 and 2048; time-major [frame][channel][2048]: 2048 and nchan * 2048)
+    const size_t chbase = (size_t)(T41RX_ABLATE == 9 ? (ch & 15) : ch) * (size_t)a.chan_stride;
+    const size_t fbase = chbase + (size_t)f * (size_t)a.frame_stride;
     const int fb = PIPE ? (f >= kSkew ? f - kSkew : 0) : f;  // the frame the back end works on
-    const size_t fbase_o = ((size_t)(T41RX_ABLATE == 9 ? (ch & 15) : ch) * a.nframes + fb) * L;
+    const size_t fbase_o = chbase + (size_t)fb * (size_t)a.frame_stride;
+    const size_t fstep = WQ15 ? (size_t)a.frame_stride / 2 : (size_t)a.frame_stride;  // this channel's next frame, in float slots
     // (WQ15: two samples per float slot, so sample offsets halve)
     const float *__restrict__ gI = a.I + (WQ15 ? fbase / 2 : fbase);
     const float *__restrict__ gQ = a.Q + (WQ15 ? fbase / 2 : fbase);
@@ -1894,25 +1911,30 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
               pI0[h] = ldg_stream(gI + o);
               pQ0[h] = ldg_stream(gQ + o);
             }
-          } else if (PART == 1 || (KEEP && kPF >= 1)) {  // the next segment's / frame's sub-blocks 0 and 1 (same channel: contiguous)
-            if (f + 1 < seg1) {
+          } else if (PART == 1 || (KEEP && kPF >= 1)) {  // the next segment's / frame's sub-blocks 0 and 1
+            // Requested UNCONDITIONALLY (the launch's last frame re-reads its own first sub-blocks, which nobody uses): a
+            // request under `if (f + 1 < seg1)` makes the register set a merge of old and new values -- 16 copies per
+            // sub-block -- and hipcc's wait for the sub-block in front of it a vmcnt(0), since it cannot count on a
+            // younger request having been issued (ISA of round 3's kernel).
+            {
+              const size_t nstep = (f + 1 < seg1) ? fstep : 0;
               if (KEEP && s == 3) {  // and the I tail that decides the next frame's Q start state
                 if (!WQ15) {
-                  tailN = *reinterpret_cast<const float4 *>(gI + L + (L - 256) + 4 * lane);
+                  tailN = *reinterpret_cast<const float4 *>(gI + nstep + (L - 256) + 4 * lane);
                 } else {  // (raw q15 words; converted when used, not here: that would wait for them)
-                  tailNq = *reinterpret_cast<const float2 *>(gI + L / 2 + (L - 256) / 2 + 2 * lane);
+                  tailNq = *reinterpret_cast<const float2 *>(gI + nstep + (L - 256) / 2 + 2 * lane);
                 }
               }
               if (KEEP && kPF < 2 && s == 3) {
                 // sub-block 1 is requested at the top of the next frame
               } else if (!WQ15) {
-                const int o = L + 512 * (s - 2) + 8 * lane;
+                const size_t o = nstep + 512 * (s - 2) + 8 * lane;
                 pI0[h] = ldg_stream(gI + o);
                 pI1[h] = ldg_stream(gI + o + 4);
                 pQ0[h] = ldg_stream(gQ + o);
                 pQ1[h] = ldg_stream(gQ + o + 4);
               } else {
-                const int o = L / 2 + 256 * (s - 2) + 4 * lane;
+                const size_t o = nstep + 256 * (s - 2) + 4 * lane;
                 pI0[h] = ldg_stream(gI + o);
                 pQ0[h] = ldg_stream(gQ + o);
               }
@@ -2859,7 +2881,22 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
       st[kStMisc + kMiscDc] = dc_carry;
     }
   }
+#ifdef T41RX_CLK
+  {
+    unsigned long long c1, r1;
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c1), "=s"(r1)::"memory");
+    if (lane == 0 && job < 8192) {
+      g_t41_clk[2 * job] = c1 - clk_c0;
+      g_t41_clk[2 * job + 1] = r1 - clk_r0;
+    }
+  }
+#endif
 }
+#ifdef T41RX_CLK
+extern "C" int t41rx_debug_read_clk(unsigned long long *host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_t41_clk), sizeof(unsigned long long) * (size_t)n);
+}
+#endif
 
 // ------------------------------------------------------------------------------------------
 // FFT_LENGTH 4096 (BASELINE config 4, a synthetic generalisation: the firmware is compiled for

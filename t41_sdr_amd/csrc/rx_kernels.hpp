@@ -37,6 +37,9 @@ struct RxArgs {
   const ChanNco *__restrict__ nco;
   int nchan;
   int nframes;
+  // where (channel c, frame f) of I / Q / out starts, in samples: c * chan_stride + f * frame_stride (t41rx_set_buffer_layout)
+  long long chan_stride;
+  long long frame_stride;
   float *dbg_nco;
   float *dbg_dec;
   float *dbg_demod;

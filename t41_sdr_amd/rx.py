@@ -74,6 +74,7 @@ class RxChain:
         self.n_channels = int(n_channels)
         self.device = int(device)
         self.frame_len = self._lib.t41rx_frame_len(self._ctx)
+        self.layout = "channel"
         if NCOFreq is not None:
             self.SetNCOFreq(NCOFreq)
 
@@ -113,6 +114,14 @@ class RxChain:
 
     def reset(self):
         check(self._lib.t41rx_reset(self._ctx))
+
+    def set_buffer_layout(self, layout):
+        """"channel" (default): I / Q / audio are [n_channels, n_frames*frame_len]; "time": [n_frames, n_channels,
+        frame_len] -- the [n_channels, frame_len] buffers of consecutive single-frame calls stacked as they arrive
+        (t41rx_set_buffer_layout; FFT_LENGTH 512)."""
+        code = {"channel": 0, "time": 1}[layout]
+        check(self._lib.t41rx_set_buffer_layout(self._ctx, code))
+        self.layout = layout
 
     def get_state(self):
         n = self._lib.t41rx_state_bytes(self._ctx)
@@ -242,6 +251,11 @@ class RxChain:
         return out
 
     def _check_shape(self, si, sq):
+        if self.layout == "time":
+            if si != sq or len(si) != 3 or si[0] == 0 or si[1] != self.n_channels or si[2] != self.frame_len:
+                raise ValueError("time-major I/Q must be [n_frames, n_channels=%d, frame_len=%d], got %r / %r"
+                                 % (self.n_channels, self.frame_len, si, sq))
+            return si[0]
         if si != sq or len(si) != 2 or si[0] != self.n_channels or si[1] == 0 or si[1] % self.frame_len:
             raise ValueError("I/Q must be [n_channels=%d, k*frame_len=%d], got %r / %r"
                              % (self.n_channels, self.frame_len, si, sq))

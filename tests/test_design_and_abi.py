@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported(T):
     assert not missing, "declared in include/t41rx.h but not exported: %s" % missing
     from t41_sdr_amd import _lib
     assert declared == set(_lib.SYMBOLS), "python binding and header disagree"
-    assert lib.t41rx_abi_version() == 4
+    assert lib.t41rx_abi_version() == 5
 
 
 def test_params_struct_layout_matches_header(T):

@@ -36,6 +36,15 @@ VARIANTS = [
     # a full kernel (correct outputs), not an ablation: the 512-point transforms' first exchange through LDS, as in
     # round 2, instead of inside the VALU (v_permlane32_swap / v_permlane16_swap / DPP; wave_fft.hpp: T41RX_FFT_X1_PERM)
     ("x1lds", "-DT41RX_FFT_X1_PERM=0", "product with the FFTs' first exchange through LDS (round 2's form) instead of v_permlane*_swap + DPP"),
+    # leave one out (round 4): the product minus exactly ONE stage, every other stage and the stores kept
+    ("loo1", "-DT41RX_LOO=1", "product without the x2 / x4 interpolators only"),
+    ("loo2", "-DT41RX_LOO=2", "product without the two 512-point FFTs + mask only"),
+    ("loo3", "-DT41RX_LOO=3", "product without the /2 decimator only"),
+    ("loo4", "-DT41RX_LOO=4", "product without the /4 decimator only"),
+    ("loo5", "-DT41RX_LOO=5", "product without the oscillator / mixer only"),
+    ("loo6", "-DT41RX_LOO=6", "product without the DC high-pass only"),
+    ("pf1", "-DT41RX_PF=1", "product with ONE sub-block of the next frame requested across the back end (16 registers fewer held)"),
+    ("pf0", "-DT41RX_PF=0", "product with none"),
 ]
 L = 2048
 ALG_BYTES_PER_FRAME = 12 * 4096 * L
@@ -54,7 +63,7 @@ def build():
         subprocess.check_call([os.path.join(ROOT, "tools", "build_variant.sh"), name, flag])
 
 
-def one(frames, reps):
+def one(frames, reps, layout="channel"):
     """HIP-event time per frame of the library this process bound (T41RX_LIB), config 2's shape"""
     sys.path.insert(0, ROOT)
     import numpy as np
@@ -63,12 +72,20 @@ def one(frames, reps):
     nch = 4096
     rng = np.random.default_rng(1000)
     nco = (rng.integers(-860, 801, nch) * 50).astype(np.int32)
-    rx = T.RxChain(nch, T.default_params(), NCOFreq=nco)
+    a = sys.argv[1:]
+    kw = {}
+    if "--mode" in a:
+        kw["mode"] = int(a[a.index("--mode") + 1])
+    if "--agc" in a:
+        kw["AGCMode"] = int(a[a.index("--agc") + 1])
+    rx = T.RxChain(nch, T.default_params(**kw), NCOFreq=nco)
+    rx.set_buffer_layout(layout)
+    shape = (nch, frames * L) if layout == "channel" else (frames, nch, L)
     ring = max(2, -(-(768 << 20) // (3 * nch * frames * L * 4)))
     g = torch.Generator(device="cuda").manual_seed(0)
-    Is = [(0.2 * torch.randn(nch, frames * L, generator=g, device="cuda")).clamp_(-0.999, 0.999) for _ in range(ring)]
-    Qs = [(0.2 * torch.randn(nch, frames * L, generator=g, device="cuda")).clamp_(-0.999, 0.999) for _ in range(ring)]
-    out = [torch.empty(nch, frames * L, device="cuda") for _ in range(ring)]
+    Is = [(0.2 * torch.randn(*shape, generator=g, device="cuda")).clamp_(-0.999, 0.999) for _ in range(ring)]
+    Qs = [(0.2 * torch.randn(*shape, generator=g, device="cuda")).clamp_(-0.999, 0.999) for _ in range(ring)]
+    out = [torch.empty(*shape, device="cuda") for _ in range(ring)]
     for k in range(max(6, reps // 4)):
         rx.ProcessIQData(Is[k % ring], Qs[k % ring], out=out[k % ring])
     torch.cuda.synchronize()
@@ -81,7 +98,7 @@ def one(frames, reps):
     return e0.elapsed_time(e1) / reps * 1e3 / frames
 
 
-def run(rounds, frames, reps, out_path):
+def run(rounds, frames, reps, out_path, layout="channel"):
     res = {name: [] for name, _, _ in VARIANTS}
     for r in range(rounds):
         for name, _, _ in VARIANTS:
@@ -92,7 +109,7 @@ def run(rounds, frames, reps, out_path):
             env.pop("T41RX_LIB", None)
             if lp:
                 env["T41RX_LIB"] = lp
-            p = subprocess.run([sys.executable, os.path.abspath(__file__), "one", name, "--frames", str(frames), "--reps", str(reps)],
+            p = subprocess.run([sys.executable, os.path.abspath(__file__), "one", name, "--frames", str(frames), "--reps", str(reps), "--layout", layout],
                                env=env, capture_output=True, text=True, timeout=600)
             cells = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
             if p.returncode != 0 or not cells:
@@ -100,7 +117,7 @@ def run(rounds, frames, reps, out_path):
                 continue
             res[name].append(cells[0]["us_per_frame"])
             print("round %d %-8s %.2f us per frame" % (r, name, cells[0]["us_per_frame"]), flush=True)
-    lines = ["# Ablation of `rx512_kernel<SSB, PLAIN>` (config 2: 4096 channels x %d frames x 2048 samples per launch)" % frames, "",
+    lines = ["# Ablation of `rx512_kernel<SSB, PLAIN>` (config 2: 4096 channels x %d frames x 2048 samples per launch, %s-major buffers)" % (frames, layout), "",
              "HIP-event time per 4096-channel frame, %d launches per cell, %d interleaved rounds, one process per cell "
              "(`tools/ablation_table.py run`).  GB/s = 12 B x 4096 x 2048 per frame over that time." % (reps, rounds), "",
              "| build | what is left | median us | min us | GB/s at the median | of 8 TB/s |", "|---|---|---|---|---|---|"]
@@ -125,6 +142,23 @@ def run(rounds, frames, reps, out_path):
             lines.append("| %s | %.2f | %.1f %% |" % (label, prev - cur, 100.0 * (prev - cur) / base))
             prev = cur
         lines.append("| memory-only skeleton (abl7) | %.2f | %.1f %% |" % (prev, 100.0 * prev / base))
+        if any(res.get("loo%d" % k) for k in range(1, 7)):
+            lines += ["", "Leave one out: the product minus exactly one stage (medians), next to that stage's cumulative figure:", "",
+                      "| stage left out | us per frame | saves | cumulative table says |", "|---|---|---|---|"]
+            cum = {}
+            prev = base
+            for name in ("abl1", "abl2", "abl3", "abl4", "abl5", "abl6"):
+                if res[name]:
+                    cur = statistics.median(res[name])
+                    cum[name[-1]] = prev - cur
+                    prev = cur
+            for k, label in ((1, "x2 + x4 interpolators"), (2, "512-point FFT, mask, inverse FFT"), (3, "/2 decimator"), (4, "/4 decimator"),
+                             (5, "oscillator + mixer"), (6, "DC high-pass")):
+                v = res.get("loo%d" % k)
+                if v:
+                    m = statistics.median(v)
+                    lines.append("| %s | %.2f | %.2f (%.1f %%) | %s |" % (label, m, base - m, 100.0 * (base - m) / base,
+                                                                     ("%.2f" % cum[str(k)]) if str(k) in cum else "-"))
     text = "\n".join(lines) + "\n"
     print(text)
     if out_path:
@@ -145,10 +179,11 @@ def main():
     if args[0] == "build":
         build()
     elif args[0] == "one":
-        us = one(opt("--frames", 32), opt("--reps", 60))
+        us = one(opt("--frames", 32), opt("--reps", 60), opt("--layout", "channel"))
         print(json.dumps({"variant": args[1] if len(args) > 1 else "product", "us_per_frame": round(us, 3)}), flush=True)
     else:
-        run(opt("--rounds", 3), opt("--frames", 32), opt("--reps", 60), opt("--out", os.path.join(ROOT, "gpurun_out", "r03_ablation_ssb.md")))
+        run(opt("--rounds", 3), opt("--frames", 32), opt("--reps", 60), opt("--out", os.path.join(ROOT, "gpurun_out", "r04_ablation_ssb.md")),
+            opt("--layout", "channel"))
 
 
 if __name__ == "__main__":

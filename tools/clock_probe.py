@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""The shader clock the fused kernel's waves see under their own load (-DT41RX_CLK diagnostic build, GPU box).
+
+  tools/build_variant.sh clk -DT41RX_CLK          (here)
+  T41RX_LIB=$PWD/t41_sdr_amd/abl/libt41rx_clk.so python tools/clock_probe.py [--agc 0] [--mode 0] [--layout channel]
+"""
+import ctypes as C
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import t41_sdr_amd as T  # noqa: E402
+from t41_sdr_amd import _lib  # noqa: E402
+
+L = 2048
+
+
+def opt(flag, default):
+    a = sys.argv[1:]
+    return type(default)(a[a.index(flag) + 1]) if flag in a else default
+
+
+def main():
+    nch, frames, reps = 4096, opt("--frames", 32), opt("--reps", 40)
+    layout = opt("--layout", "channel")
+    rx = T.RxChain(nch, T.default_params(mode=opt("--mode", 0), AGCMode=opt("--agc", 0)),
+                   NCOFreq=(np.random.default_rng(1000).integers(-860, 801, nch) * 50).astype(np.int32))
+    rx.set_buffer_layout(layout)
+    shape = (nch, frames * L) if layout == "channel" else (frames, nch, L)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    ring = 3
+    Is = [(0.2 * torch.randn(*shape, generator=g, device="cuda")).clamp_(-0.999, 0.999) for _ in range(ring)]
+    Qs = [(0.2 * torch.randn(*shape, generator=g, device="cuda")).clamp_(-0.999, 0.999) for _ in range(ring)]
+    out = [torch.empty(*shape, device="cuda") for _ in range(ring)]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for k in range(10):
+        rx.ProcessIQData(Is[k % ring], Qs[k % ring], out=out[k % ring])
+    e0.record()
+    for k in range(reps):
+        rx.ProcessIQData(Is[k % ring], Qs[k % ring], out=out[k % ring])
+    e1.record()
+    torch.cuda.synchronize()
+    lib = _lib.load()
+    buf = (C.c_ulonglong * (2 * nch))()
+    rc = lib.t41rx_debug_read_clk(buf, 2 * nch)
+    a = np.frombuffer(buf, dtype=np.uint64).astype(np.float64).reshape(nch, 2)
+    ghz = a[:, 0] / a[:, 1] * 0.1
+    print(json.dumps({"rc": rc, "us_per_frame": round(e0.elapsed_time(e1) / reps * 1e3 / frames, 3),
+                      "clock_GHz_median": round(float(np.median(ghz)), 3), "min": round(float(ghz.min()), 3), "max": round(float(ghz.max()), 3),
+                      "wave_life_us_median": round(float(np.median(a[:, 1])) / 100.0, 1),
+                      "cycles_per_wave_frame": round(float(np.median(a[:, 0])) / frames)}), flush=True)
+
+
+if __name__ == "__main__":
+    main()

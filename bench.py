@@ -44,6 +44,9 @@ WORKLOADS = {
     "ssb": dict(batch=4096, fft=512, kw=dict(mode=0, FLoCut=200, FHiCut=3000),
                 name="configs[1]: batched SSB (USB 200-3000 Hz) RX chain, decimate-by-8 + 512-pt fast-conv + demod + "
                      "interpolate-by-8, 4096 channels x 2048 complex f32 samples per frame per GPU, per-channel NCO, AGC off"),
+    "ssb_time_major": dict(batch=4096, fft=512, kw=dict(mode=0, FLoCut=200, FHiCut=3000), layout="time",
+                           name="configs[1] with the call's frames stacked as [frame][channel][2048] (t41rx_set_buffer_layout: the buffers "
+                                "of consecutive single-frame calls as they arrive) instead of [channel][frames x 2048]"),
     "nfm": dict(batch=4096, fft=512, kw=dict(mode=3, FLoCut=200, FHiCut=3000, nfmFilterBW=12000),
                 name="configs[2]: NFM path as the firmware runs it (quadri-correlator + limiter + real overlap-save audio "
                      "filter), 4096 channels x 2048 samples per frame"),
@@ -375,6 +378,17 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
+    # which physical device every rank runs on: N ranks must sit on N distinct GPUs (rank 0 checks, the line reports)
+    props = torch.cuda.get_device_properties(local_rank)
+    my_dev = "%s %s" % (getattr(props, "uuid", "no-uuid-%d" % local_rank), props.name)
+    devices = [my_dev]
+    if dist is not None:
+        devices = [None] * world
+        dist.all_gather_object(devices, my_dev)
+    print("rank %d of %d: LOCAL_RANK %d -> %s" % (rank, world, local_rank, my_dev), file=sys.stderr, flush=True)
+    if len(set(devices)) != len(devices):
+        raise SystemExit("two ranks run on the same device: %r" % (devices,))
+
     head = Workload(torch, T, args.workload, world, rank, local_rank, dev, dist, args.frames_per_launch)
     wall, kernel_ms = head.time(args.steps, args.warmup)
     if not head.q15 and not os.environ.get("T41RX_BENCH_NOCHECK") and not torch.isfinite(head.outs[(args.warmup + args.steps - 1) % head.ring]).all():
@@ -399,7 +413,9 @@ def main():
             "workload": wl["name"],
             "batch": head.n, "frame_len": head.frame_len, "fft_length": head.fft_length,
             "frames_per_launch": head.frames,
+            "buffer_layout": head.layout + "-major",
             "world_size_observed": observed,
+            "devices": devices,
             "parallelism": "channels sharded per GPU (one process per GPU), one-shot RCCL coefficient broadcast, no data-path collective",
         },
         "roofline": head.roofline(kernel_ms),
@@ -417,14 +433,16 @@ def main():
     if rank == 0 and world == 1 and args.workload == "ssb" and not args.no_other_workloads:
         # BASELINE configs[2] / [3] and the firmware's default AGC mode, timed in this same run
         others = {}
-        for name in ("nfm", "fft4096", "ssb_agc"):
+        for name in ("nfm", "fft4096", "ssb_agc", "ssb_time_major"):
             w = Workload(torch, T, name, 1, 0, local_rank, dev, None, 0)
             _, kms = w.time(12, 4)
             r = w.roofline(kms)
             entry = {"workload": w.wl["name"], "batch": w.n, "frames_per_launch": w.frames, "kernel_ms": r["kernel_ms"],
                      "us_per_frame": r["us_per_frame"], "frac": r["frac"], "achieved_GBs": r["achieved"], "traffic": r["traffic"]}
             if not os.environ.get("T41RX_BENCH_NOCHECK"):
-                entry["parity_check"] = parity_check(torch, w, 2, 16)
+                # every launch of this workload's run (4 warm-up + 12 timed), replayed and compared with the oracle; the
+                # replay must reproduce the timed pass bit for bit (round 3 checked 2 of the 16 and could not assert that)
+                entry["parity_check"] = parity_check(torch, w, 16, 16, sample=8 if w.fft_length == 4096 else 16)
             others[name] = entry
             w.free()
         line["other_workloads"] = others
@@ -472,6 +490,11 @@ class Workload:
         self.ring = max(2, -(-(768 << 20) // bytes_per_buf))
         self.Is, self.Qs = synth_ring(torch, self.n, self.nco, self.ring, self.frames, self.frame_len, dev, seed=0x5441315F + rank,
                                       mode=params.mode, flo=params.FLoCut, fhi=params.FHiCut)
+        self.layout = wl.get("layout", "channel")
+        if self.layout == "time":  # [frame][channel][frame_len]
+            self.rx.set_buffer_layout("time")
+            self.Is = [x.view(self.n, self.frames, self.frame_len).transpose(0, 1).contiguous() for x in self.Is]
+            self.Qs = [x.view(self.n, self.frames, self.frame_len).transpose(0, 1).contiguous() for x in self.Qs]
         self.q15 = bool(wl.get("q15"))
         self.bytes_per_sample = 6.0 if self.q15 else BYTES_PER_SAMPLE  # 2 x int16 in + int16 out
         if self.q15:  # what the codec would deliver for these waveforms
@@ -479,6 +502,12 @@ class Workload:
             self.Qs = [(x * 32768.0).round_().clamp_(-32768, 32767).to(torch.int16) for x in self.Qs]
         self.outs = [torch.empty_like(x) for x in self.Is]
         self.samples_per_step = self.n * self.frames * self.frame_len
+
+    def channels_of(self, x, idx_t):
+        """the sampled channels of a launch buffer as [len(idx), frames * frame_len], whatever the layout"""
+        if self.layout == "time":
+            return x.index_select(1, idx_t).transpose(0, 1).reshape(idx_t.numel(), -1)
+        return x.index_select(0, idx_t)
 
     def step(self, k):
         r = k % self.ring
@@ -557,15 +586,15 @@ def parity_check(torch, w, launches, launches_timed, sample=16):
     got = []
     for k in range(launches):
         w.step(k)
-        got.append(w.outs[k % w.ring].index_select(0, idx_t))
+        got.append(w.channels_of(w.outs[k % w.ring], idx_t))
     torch.cuda.synchronize()
     replay_identical = None
     if left is not None:
         replay_identical = all(torch.equal(a, b) for a, b in zip(left, w.outs))
     ob = O.OracleBatch(O.default_params(**w.params_kw), np.asarray(w.nco[idx], dtype=np.int32), native=False)
     threads = max(1, min(host_cpu()[2], len(idx)))
-    hI = [x.index_select(0, idx_t).cpu().numpy() for x in w.Is]
-    hQ = [x.index_select(0, idx_t).cpu().numpy() for x in w.Qs]
+    hI = [w.channels_of(x, idx_t).cpu().numpy() for x in w.Is]
+    hQ = [w.channels_of(x, idx_t).cpu().numpy() for x in w.Qs]
     worst, worst_at, sq_err, sq_ref = 0.0, None, 0.0, 0.0
     for k in range(launches):
         r = k % w.ring

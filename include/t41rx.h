@@ -182,8 +182,10 @@ int t41rx_process_host(t41rx_ctx *ctx, const float *I, const float *Q, float *au
  *   &float_buffer_R[...])                     Process.cpp:107-108 (note the swap: I comes from the R queue)
  *   arm_float_to_q15(float_buffer_L, q15_buffer_LTemp, 2048); Q_out_L.play(...)    Process.cpp:936-937
  * with CMSIS-DSP's conversions (x / 32768; truncating, saturating (q15_t)__SSAT((q31_t)(x * 32768), 16)).
- * Layout [n_channels][n_frames*frame_len] int16, the 16 blocks of 128 of a frame back to back.
- * Not available while debug taps or the audio-spectrum output are set. */
+ * Layout [n_channels][n_frames*frame_len] int16, the 16 blocks of 128 of a frame back to back (or time-major,
+ * t41rx_set_buffer_layout).  The side outputs and stage taps work here as on the f32 entry points (ABI 5): the
+ * reference computes its display FFT and audio spectrum inside every ProcessIQData() call on exactly these q15-fed
+ * buffers (Process.cpp:107-108 -> :184-186, :211-215, :550-570). */
 int t41rx_process_device_q15(t41rx_ctx *ctx, const int16_t *dQ_in_L, const int16_t *dQ_in_R,
                              int16_t *dQ_out_L, int n_frames, void *hip_stream);
 int t41rx_process_host_q15(t41rx_ctx *ctx, const int16_t *Q_in_L, const int16_t *Q_in_R,
@@ -221,7 +223,7 @@ int t41rx_set_debug_taps(t41rx_ctx *ctx, float *d_post_nco, float *d_dec, float 
  *   d_spect : [n_channels][n_frames][1024]  audioSpectBuffer
  *   d_max   : [n_channels][n_frames][3]     audioMaxSquared, (float)AudioMaxIndex, audioMaxSquaredAve
  * and updates the per-channel audioMaxSquaredAve.  The pixel mapping (audioYPixel) is display
- * code and stays with the caller.  fft_length 512, f32 entry points only.  max_frames as above. */
+ * code and stays with the caller.  fft_length 512; f32 and q15 entry points.  max_frames as above. */
 int t41rx_set_audio_spectrum(t41rx_ctx *ctx, float *d_spect, float *d_max, int max_frames);
 
 /* ---- the display FFT: what ShowSpectrum() draws from (FFT.cpp:67-251) ----
@@ -236,7 +238,7 @@ int t41rx_set_audio_spectrum(t41rx_ctx *ctx, float *d_spect, float *d_max, int m
  *   d_spec     : [n_channels][n_frames][512]  FFT_spec
  *   d_spec_old : [n_channels][n_frames][512]  FFT_spec_old
  * Setting it (or changing spectrumZoom) starts from cleared zoom filters, ring and low-pass memory.
- * fft_length 512, f32 entry points only; max_frames as for the stage taps. */
+ * fft_length 512; f32 and q15 entry points; max_frames as for the stage taps. */
 int t41rx_set_display_spectrum(t41rx_ctx *ctx, float *d_spec, float *d_spec_old, int spectrumZoom, int max_frames);
 
 #ifdef __cplusplus

@@ -273,6 +273,7 @@ __global__ __launch_bounds__(64) void nrspec_kernel(const NrArgs a) {
     Xt[i] = st[kNrXt + i];
     Hk[i] = st[kNrHk + i];
   }
+  float lastX[2] = {0.0f, 0.0f};
   int xp = (int)st[kNrScal + 0], ep = (int)st[kNrScal + 1], first_time_2 = (int)st[kNrScal + 2], init_counter = (int)st[kNrScal + 3];
   const int lo = a.vad_lo, hi = a.vad_hi;
   const float NR_alpha = a.alpha, NR_beta = a.beta, NR_PSI = a.psi;
@@ -341,6 +342,10 @@ __global__ __launch_bounds__(64) void nrspec_kernel(const NrArgs a) {
       for (int k2 = 0; k2 < 2; ++k2) X[k2][r] = F[k2][r].x * F[k2][r].x + F[k2][r].y * F[k2][r].y;
     }
     const cf z128 = Zs[128];  // F0[128] = Re, F1[128] = Im
+    if (KIND == 2) {  // NR_X[bindx][0] as the call's last half-block leaves it (Noise.cpp:478), for the record
+      lastX[0] = X[1][0];
+      lastX[1] = X[1][1];
+    }
     bool proc[2] = {true, true};
 #pragma unroll
     for (int k2 = 0; k2 < 2; ++k2) {
@@ -450,6 +455,33 @@ __global__ __launch_bounds__(64) void nrspec_kernel(const NrArgs a) {
             }
             const float post_power = wave_sum(post_part);
             float power_ratio = post_power / pre_power;
+            // The reference adds both sums up bin by bin in float (Noise.cpp:542-546); the tree sums above differ from
+            // that by rounding only, and all that is ever derived from the ratio is NN, which changes at 0.4, 0.35, 0.25,
+            // 0.15 and 0.05.  Next to one of those the sums are redone in the reference's order (every lane, the same
+            // values through LDS), so NN is decided exactly as the scalar code decides it.
+            {
+              bool near_edge = false;
+#pragma unroll
+              for (float b : {0.4f, 0.35f, 0.25f, 0.15f, 0.05f}) near_edge = near_edge || fabsf(power_ratio - b) < 4e-5f;
+              if (near_edge) {
+                float *Pw = U + 640;  // (free between the transforms: the spectra occupy U[0 .. 520))
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                  const int j = lane + 64 * r;
+                  Pw[j] = X[k2][r];
+                  Pw[128 + j] = Gst[j] * Gst[j] * X[k2][r];
+                }
+                __syncthreads();
+                float pre_seq = 0.0f, post_seq = 0.0f;
+                for (int j = lo; j < hi; ++j) {
+                  pre_seq += Pw[j];
+                  post_seq += Pw[128 + j];
+                }
+                power_ratio = post_seq / pre_seq;
+                __syncthreads();
+              }
+            }
             int NN;
             if (power_ratio > power_threshold) {
               power_ratio = 1.0;
@@ -561,9 +593,14 @@ __global__ __launch_bounds__(64) void nrspec_kernel(const NrArgs a) {
     __syncthreads();
   }
   // ---- the record back
-  if (KIND == 1) {  // (the spectral function keeps NR_X[.][0] only within a frame and never touches NR_E)
+  if (KIND == 1) {
     for (int i = lane; i < 3 * 128; i += 64) st[kNrX + i] = (&Xs[0][0])[i];
     for (int i = lane; i < 15 * 128; i += 64) st[kNrE + i] = (&Es[0][0])[i];
+  } else if (a.nframes > 0) {
+    // the spectral function stores NR_X[.][0] every frame and never touches NR_X[.][1..2] or NR_E: what Kim1_NR()'s
+    // three-frame average starts from after a live switch of nrOptionSelect from 2 to 1, as in the firmware
+    st[kNrX + lane] = lastX[0];
+    st[kNrX + 64 + lane] = lastX[1];
   }
   for (int i = lane; i < 128; i += 64) {
     if (KIND == 1) {

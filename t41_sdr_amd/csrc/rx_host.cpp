@@ -226,6 +226,16 @@ int upload_coeffs(t41rx_ctx *ctx) {
   return T41RX_OK;
 }
 
+// InitializeDataArrays() + SpectralNoiseReductionInit() (T41_SDR.ino:479-504, 657)
+int reset_nr(t41rx_ctx *ctx) {
+  std::vector<float> anr((size_t)kAnrStRows * (size_t)ctx->nchan), spec((size_t)kNrSpecFloats * (size_t)ctx->nchan);
+  nr_reset_anr(anr.data(), (size_t)ctx->nchan);
+  for (int c = 0; c < ctx->nchan; ++c) nr_reset_record(spec.data() + (size_t)kNrSpecFloats * (size_t)c);
+  HIP_TRY(hipMemcpy(ctx->d_nr_anr, anr.data(), sizeof(float) * anr.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(ctx->d_nr_spec, spec.data(), sizeof(float) * spec.size(), hipMemcpyHostToDevice));
+  return T41RX_OK;
+}
+
 int reset_state(t41rx_ctx *ctx) {
   const size_t sf = state_floats(ctx->params.fft_length);
   std::vector<float> h(sf * (size_t)ctx->nchan, 0.0f);
@@ -239,13 +249,7 @@ int reset_state(t41rx_ctx *ctx) {
   HIP_TRY(hipMemcpy(ctx->d_state, h.data(), sizeof(float) * h.size(), hipMemcpyHostToDevice));
   ctx->nco_sel = 0;
   if (ctx->d_disp) HIP_TRY(hipMemset(ctx->d_disp, 0, sizeof(float) * kDispFloats * (size_t)ctx->nchan));
-  if (ctx->d_nr_anr) {  // InitializeDataArrays() + SpectralNoiseReductionInit() (T41_SDR.ino:479-504, 657)
-    std::vector<float> anr((size_t)kAnrStRows * (size_t)ctx->nchan), spec((size_t)kNrSpecFloats * (size_t)ctx->nchan);
-    nr_reset_anr(anr.data(), (size_t)ctx->nchan);
-    for (int c = 0; c < ctx->nchan; ++c) nr_reset_record(spec.data() + (size_t)kNrSpecFloats * (size_t)c);
-    HIP_TRY(hipMemcpy(ctx->d_nr_anr, anr.data(), sizeof(float) * anr.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(ctx->d_nr_spec, spec.data(), sizeof(float) * spec.size(), hipMemcpyHostToDevice));
-  }
+  if (ctx->d_nr_anr) return reset_nr(ctx);
   return T41RX_OK;
 }
 
@@ -495,13 +499,17 @@ int t41rx_set_nco_freq(t41rx_ctx *ctx, const int32_t *nco_freq_hz, int n) {
   return upload_nco(ctx);
 }
 
+static int pipe_timeouts_clear(t41rx_ctx *ctx);
+static int pipe_status(t41rx_ctx *ctx);
+
 int t41rx_reset(t41rx_ctx *ctx) {
   if (!ctx) return fail(T41RX_ERR_ARG, "null argument");
   DeviceGuard g(ctx->device);
   HIP_TRY(hipDeviceSynchronize());
-  if (ctx->d_agc_pipe)  // (and the pipelined kernels' time-out counter, see pipe_timeouts)
-    HIP_TRY(hipMemset(reinterpret_cast<char *>(ctx->d_agc_pipe) + (size_t)ctx->nchan * 3 * 1024 * sizeof(float) +
-                          ((size_t)ctx->nchan + 15) * 16 * sizeof(unsigned long long), 0, sizeof(unsigned long long)));
+  {  // (and the pipelined kernels' time-out counter)
+    const int rc = pipe_timeouts_clear(ctx);
+    if (rc != T41RX_OK) return rc;
+  }
   return reset_state(ctx);
 }
 
@@ -532,8 +540,6 @@ int t41rx_process_device(t41rx_ctx *ctx, const float *dI, const float *dQ, float
 // (Process.cpp:107-108)
 int t41rx_process_device_q15(t41rx_ctx *ctx, const int16_t *dQ_in_L, const int16_t *dQ_in_R, int16_t *dQ_out_L,
                              int n_frames, void *hip_stream) {
-  if (ctx && (ctx->dbg_nco || ctx->dbg_dec || ctx->dbg_demod || ctx->spect))
-    return fail(T41RX_ERR_UNSUPPORTED, "debug taps / the audio spectrum are not available on the q15 entry points");
   return process_device_impl(ctx, reinterpret_cast<const float *>(dQ_in_R), reinterpret_cast<const float *>(dQ_in_L),
                              reinterpret_cast<float *>(dQ_out_L), n_frames, hip_stream, true);
 }
@@ -618,8 +624,14 @@ int process_device_impl(t41rx_ctx *ctx, const float *dI, const float *dQ, float 
   if ((a.agc != 0) != (ctx->params.mode == T41RX_DEMOD_SAM) && seg == 1 && n_frames >= 4) {
     if (!ctx->d_agc_pipe) {  // (+ 8 counters per wave of the -DT41RX_PIPE_STAT diagnostic build)
       const size_t bytes = (size_t)ctx->nchan * 3 * 1024 * sizeof(float) + ((size_t)ctx->nchan + 16) * 16 * sizeof(unsigned long long);
-      HIP_TRY(hipMalloc((void **)&ctx->d_agc_pipe, bytes));
-      HIP_TRY(hipMemset(ctx->d_agc_pipe, 0, bytes));
+      float *slots = nullptr;  // the context only ever sees a buffer whose counters are zero
+      HIP_TRY(hipMalloc((void **)&slots, bytes));
+      const hipError_t em = hipMemset(slots, 0, bytes);
+      if (em != hipSuccess) {
+        (void)hipFree(slots);
+        return hip_fail(em, "hipMemset of the pipelined kernels' slots");
+      }
+      ctx->d_agc_pipe = slots;
     }
     a.agc_pipe = ctx->d_agc_pipe;
   }
@@ -631,7 +643,6 @@ int process_device_impl(t41rx_ctx *ctx, const float *dI, const float *dQ, float 
     return fail(T41RX_ERR_ARG, "n_frames exceeds the max_frames the audio-spectrum buffers were set with");
   if (ctx->disp_spec && n_frames > ctx->disp_frames)
     return fail(T41RX_ERR_ARG, "n_frames exceeds the max_frames the display-spectrum buffers were set with");
-  if (ctx->disp_spec && q15) return fail(T41RX_ERR_UNSUPPORTED, "the display spectrum is not available on the q15 entry points");
   if (ctx->disp_spec && (!ctx->d_pre || !ctx->d_disp || !ctx->d_win)) return fail(T41RX_ERR_STATE, "display spectrum enabled without its buffers");
   a.dbg_pre = ctx->disp_spec ? ctx->d_pre : nullptr;
   a.dbg_nco = ctx->dbg_nco;
@@ -719,7 +730,7 @@ int t41rx_process_host_q15(t41rx_ctx *ctx, const int16_t *Q_in_L, const int16_t 
   if (rc != T41RX_OK) return rc;
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(Q_out_L, ctx->d_out, bytes, hipMemcpyDeviceToHost));
-  return T41RX_OK;
+  return pipe_status(ctx);  // (these calls synchronise: samples of a run whose hand-over broke do not leave with OK)
 }
 
 int t41rx_process_host(t41rx_ctx *ctx, const float *I, const float *Q, float *audio, int n_frames) {
@@ -738,7 +749,7 @@ int t41rx_process_host(t41rx_ctx *ctx, const float *I, const float *Q, float *au
   if (rc != T41RX_OK) return rc;
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(audio, ctx->d_out, nfl * sizeof(float), hipMemcpyDeviceToHost));
-  return T41RX_OK;
+  return pipe_status(ctx);  // (these calls synchronise: samples of a run whose hand-over broke do not leave with OK)
 }
 
 namespace {
@@ -746,20 +757,49 @@ constexpr uint32_t kStateMagic = 0x54343153u;  // "T41S"
 constexpr size_t kStateHeaderBytes = 32;
 }  // namespace
 
+// Checkpoint sections behind the path's records (header word 5 = which are present):
+//   bit 0  noise reduction / notch: Xanr()'s taps, delay line and leak words [kAnrStRows][n_channels], then the
+//          Kim / spectral records [n_channels][kNrSpecFloats] (Noise.cpp:19-56) -- present once the stages have run
+//   bit 1  display FFT: zoom filters, ring, FFT_spec_old [n_channels][kDispFloats] (FFT.cpp:14-26) -- present while
+//          t41rx_set_display_spectrum is on; header word 6 = its spectrumZoom
+constexpr int32_t kSecNr = 1, kSecDisp = 2;
+static size_t nr_section_bytes(int nchan) { return sizeof(float) * ((size_t)kAnrStRows + (size_t)kNrSpecFloats) * (size_t)nchan; }
+static size_t disp_section_bytes(int nchan) { return sizeof(float) * (size_t)kDispFloats * (size_t)nchan; }
+static int32_t state_sections(const t41rx_ctx *ctx) {
+  return (ctx->d_nr_anr ? kSecNr : 0) | ((ctx->disp_spec && ctx->d_disp) ? kSecDisp : 0);
+}
+
 size_t t41rx_state_bytes(const t41rx_ctx *ctx) {
   if (!ctx) return 0;
-  return kStateHeaderBytes + sizeof(float) * state_floats(ctx->params.fft_length) * (size_t)ctx->nchan;
+  const int32_t sec = state_sections(ctx);
+  return kStateHeaderBytes + sizeof(float) * state_floats(ctx->params.fft_length) * (size_t)ctx->nchan +
+         ((sec & kSecNr) ? nr_section_bytes(ctx->nchan) : 0) + ((sec & kSecDisp) ? disp_section_bytes(ctx->nchan) : 0);
 }
 
 // the pipelined kernels count a wait that ran out (rx_kernels.hip: pipe_wait_ge) behind their slots: a broken hand-over
 // protocol would leave wrong samples, not a hung GPU -- reported at the calls that synchronise anyway
-static int pipe_timeouts(t41rx_ctx *ctx) {
+static size_t pipe_timeout_offset(const t41rx_ctx *ctx) {
+  return (size_t)ctx->nchan * 3 * 1024 * sizeof(float) + ((size_t)ctx->nchan + 15) * 16 * sizeof(unsigned long long);
+}
+static int pipe_timeouts(t41rx_ctx *ctx) {  // < 0: the counter could not be read
   if (!ctx->d_agc_pipe) return 0;
   unsigned n = 0;
-  const char *p = reinterpret_cast<const char *>(ctx->d_agc_pipe) + (size_t)ctx->nchan * 3 * 1024 * sizeof(float) +
-                  ((size_t)ctx->nchan + 15) * 16 * sizeof(unsigned long long);
+  const char *p = reinterpret_cast<const char *>(ctx->d_agc_pipe) + pipe_timeout_offset(ctx);
   if (hipMemcpy(&n, p, sizeof(n), hipMemcpyDeviceToHost) != hipSuccess) return -1;
   return (int)n;
+}
+static int pipe_timeouts_clear(t41rx_ctx *ctx) {
+  if (!ctx->d_agc_pipe) return T41RX_OK;
+  HIP_TRY(hipMemset(reinterpret_cast<char *>(ctx->d_agc_pipe) + pipe_timeout_offset(ctx), 0, sizeof(unsigned long long)));
+  return T41RX_OK;
+}
+// what the synchronising entry points answer when a wait inside the pipelined kernels has run out
+static int pipe_status(t41rx_ctx *ctx) {
+  const int n = pipe_timeouts(ctx);
+  if (n < 0) return fail(T41RX_ERR_HIP, "could not read the pipelined kernels' time-out counter");
+  if (n > 0)
+    return fail(T41RX_ERR_STATE, "a wait inside the pipelined AGC / SAM kernel ran out: the samples since the last reset or restored checkpoint are not valid");
+  return T41RX_OK;
 }
 
 int t41rx_get_state(t41rx_ctx *ctx, void *host_buf, size_t bytes) {
@@ -767,31 +807,78 @@ int t41rx_get_state(t41rx_ctx *ctx, void *host_buf, size_t bytes) {
   if (bytes < t41rx_state_bytes(ctx)) return fail(T41RX_ERR_STATE, "state buffer too small");
   DeviceGuard g(ctx->device);
   HIP_TRY(hipDeviceSynchronize());
-  if (pipe_timeouts(ctx) != 0) return fail(T41RX_ERR_STATE, "a wait inside the pipelined AGC / SAM kernel ran out: the samples since the last checkpoint are not valid");
+  {
+    const int rc = pipe_status(ctx);
+    if (rc != T41RX_OK) return rc;
+  }
+  const int32_t sec = state_sections(ctx);
   int32_t hdr[8] = {(int32_t)kStateMagic, T41RX_ABI_VERSION, ctx->params.fft_length, ctx->nchan,
-                    (int32_t)state_floats(ctx->params.fft_length), 0, 0, 0};
+                    (int32_t)state_floats(ctx->params.fft_length), sec, (sec & kSecDisp) ? ctx->disp_zoom : 0, 0};
   std::memcpy(host_buf, hdr, sizeof(hdr));
-  HIP_TRY(hipMemcpy(static_cast<char *>(host_buf) + kStateHeaderBytes, ctx->d_state,
-                    t41rx_state_bytes(ctx) - kStateHeaderBytes, hipMemcpyDeviceToHost));
+  const size_t path_bytes = sizeof(float) * state_floats(ctx->params.fft_length) * (size_t)ctx->nchan;
+  char *out = static_cast<char *>(host_buf) + kStateHeaderBytes;
+  HIP_TRY(hipMemcpy(out, ctx->d_state, path_bytes, hipMemcpyDeviceToHost));
   // canonical checkpoint: the current oscillator state in both slots
-  float *rec = reinterpret_cast<float *>(static_cast<char *>(host_buf) + kStateHeaderBytes);
+  float *rec = reinterpret_cast<float *>(out);
   const size_t sf = state_floats(ctx->params.fft_length);
   for (int c = 0; c < ctx->nchan; ++c) {
     float *n = rec + sf * (size_t)c + kStNco;
     std::memcpy(n + 4 * (ctx->nco_sel ^ 1), n + 4 * ctx->nco_sel, sizeof(NcoState));
   }
+  out += path_bytes;
+  if (sec & kSecNr) {
+    const size_t ab = sizeof(float) * (size_t)kAnrStRows * (size_t)ctx->nchan;
+    HIP_TRY(hipMemcpy(out, ctx->d_nr_anr, ab, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out + ab, ctx->d_nr_spec, nr_section_bytes(ctx->nchan) - ab, hipMemcpyDeviceToHost));
+    out += nr_section_bytes(ctx->nchan);
+  }
+  if (sec & kSecDisp) HIP_TRY(hipMemcpy(out, ctx->d_disp, disp_section_bytes(ctx->nchan), hipMemcpyDeviceToHost));
   return T41RX_OK;
 }
 
 int t41rx_set_state(t41rx_ctx *ctx, const void *host_buf, size_t bytes) {
   if (!ctx || !host_buf) return fail(T41RX_ERR_ARG, "null argument");
-  if (bytes != t41rx_state_bytes(ctx)) return fail(T41RX_ERR_STATE, "state size mismatch");
+  if (bytes < kStateHeaderBytes) return fail(T41RX_ERR_STATE, "state size mismatch");
   int32_t hdr[8];
   std::memcpy(hdr, host_buf, sizeof(hdr));
   const size_t sf = state_floats(ctx->params.fft_length);
   if ((uint32_t)hdr[0] != kStateMagic || hdr[1] != T41RX_ABI_VERSION || hdr[2] != ctx->params.fft_length ||
       hdr[3] != ctx->nchan || hdr[4] != (int32_t)sf)
     return fail(T41RX_ERR_STATE, "checkpoint header does not match this context (magic / abi / fft_length / channels)");
+  const int32_t sec = hdr[5];
+  if (sec & ~(kSecNr | kSecDisp)) return fail(T41RX_ERR_STATE, "checkpoint: unknown sections");
+  const size_t path_bytes = sizeof(float) * sf * (size_t)ctx->nchan;
+  if (bytes != kStateHeaderBytes + path_bytes + ((sec & kSecNr) ? nr_section_bytes(ctx->nchan) : 0) +
+                   ((sec & kSecDisp) ? disp_section_bytes(ctx->nchan) : 0))
+    return fail(T41RX_ERR_STATE, "state size mismatch");
+  if ((sec & kSecNr) && ctx->params.fft_length != 512) return fail(T41RX_ERR_STATE, "checkpoint: noise-reduction section at a long fft_length");
+  if (sec & kSecDisp) {
+    if (!(ctx->disp_spec && ctx->d_disp)) return fail(T41RX_ERR_STATE, "checkpoint carries display-FFT state but the display spectrum is off here");
+    if (hdr[6] != ctx->disp_zoom) return fail(T41RX_ERR_STATE, "checkpoint: display-FFT state of another spectrumZoom");
+  }
+  const char *nr_sec = static_cast<const char *>(host_buf) + kStateHeaderBytes + path_bytes;
+  const char *disp_sec = nr_sec + ((sec & kSecNr) ? nr_section_bytes(ctx->nchan) : 0);
+  if (sec & kSecNr) {
+    // what the kernels index with or divide by (nr_kernels.hip): Xanr()'s leak index, the spectral functions' ring pointers
+    const float *anr = reinterpret_cast<const float *>(nr_sec);
+    const float *spec = anr + (size_t)kAnrStRows * (size_t)ctx->nchan;
+    for (int c = 0; c < ctx->nchan; ++c) {
+      const float lidx = anr[(size_t)kAnrStLidx * ctx->nchan + c], ng = anr[(size_t)kAnrStNgamma * ctx->nchan + c];
+      if (!(lidx >= 0.0f && lidx <= 1000.0f) || !std::isfinite(ng)) return fail(T41RX_ERR_STATE, "checkpoint: notch leak words out of range");
+      const float *sc = spec + (size_t)kNrSpecFloats * (size_t)c + kNrScal;
+      if (!(sc[0] >= 0.0f && sc[0] <= 2.0f) || !(sc[1] >= 0.0f && sc[1] <= 14.0f) || !(sc[2] == 0.0f || sc[2] == 1.0f || sc[2] == 2.0f) ||
+          !(sc[3] >= 0.0f && sc[3] <= 1.0e6f))
+        return fail(T41RX_ERR_STATE, "checkpoint: noise-reduction ring pointers out of range");
+    }
+  }
+  if (sec & kSecDisp) {
+    const float *d = reinterpret_cast<const float *>(disp_sec);
+    for (int c = 0; c < ctx->nchan; ++c) {
+      int32_t ptr;
+      std::memcpy(&ptr, d + (size_t)kDispFloats * (size_t)c + kDispPtr, sizeof(ptr));
+      if (ptr < 0 || ptr >= 512) return fail(T41RX_ERR_STATE, "checkpoint: zoom_sample_ptr out of range");
+    }
+  }
   // what the kernels consume as it stands: the oscillator amplitude and the AGC state words
   const float *rec = reinterpret_cast<const float *>(static_cast<const char *>(host_buf) + kStateHeaderBytes);
   const size_t ag = st_agc(ctx->params.fft_length) + kAgcHistFloats;
@@ -815,9 +902,28 @@ int t41rx_set_state(t41rx_ctx *ctx, const void *host_buf, size_t bytes) {
   }
   DeviceGuard g(ctx->device);
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(ctx->d_state, rec, bytes - kStateHeaderBytes, hipMemcpyHostToDevice));
+  if (sec & kSecNr) {
+    const int rc = ensure_nr(ctx);
+    if (rc != T41RX_OK) return rc;
+  }
+  HIP_TRY(hipMemcpy(ctx->d_state, rec, path_bytes, hipMemcpyHostToDevice));
   ctx->nco_sel = 0;  // (a checkpoint carries the current oscillator state in both slots)
-  return T41RX_OK;
+  // The side stages' memories follow the checkpoint too: restored where it carries them, back to power-on where it
+  // does not (a checkpoint taken before the stages first ran) -- never the values of the stream being replaced.
+  if (sec & kSecNr) {
+    const size_t ab = sizeof(float) * (size_t)kAnrStRows * (size_t)ctx->nchan;
+    HIP_TRY(hipMemcpy(ctx->d_nr_anr, nr_sec, ab, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->d_nr_spec, nr_sec + ab, nr_section_bytes(ctx->nchan) - ab, hipMemcpyHostToDevice));
+  } else if (ctx->d_nr_anr) {
+    const int rc = reset_nr(ctx);
+    if (rc != T41RX_OK) return rc;
+  }
+  if (sec & kSecDisp) {
+    HIP_TRY(hipMemcpy(ctx->d_disp, disp_sec, disp_section_bytes(ctx->nchan), hipMemcpyHostToDevice));
+  } else if (ctx->d_disp) {
+    HIP_TRY(hipMemset(ctx->d_disp, 0, sizeof(float) * kDispFloats * (size_t)ctx->nchan));  // ZoomFFTPrep()
+  }
+  return pipe_timeouts_clear(ctx);  // the restored state is valid again
 }
 
 int t41rx_set_debug_taps(t41rx_ctx *ctx, float *d_post_nco, float *d_dec, float *d_demod, int max_frames) {

@@ -3997,7 +3997,12 @@ static hipError_t launch512(const RxArgs &a, hipStream_t s, bool debug) {
       return hipGetLastError();
     }
   }
-  if (a.q15) {  // the firmware's q15 sample format either side (no debug taps: refused by the host)
+  if (a.q15 && debug) {  // q15 samples either side with the side outputs / stage taps (round 4; general front end)
+    if (a.agc)
+      T41RX_GO(true, false, true, true);
+    else
+      T41RX_GO(true, false, false, true);
+  } else if (a.q15) {  // the firmware's q15 sample format either side
     if (a.agc) {
       if (a.plain)
         T41RX_GO(false, true, true, true);
@@ -4157,7 +4162,10 @@ hipError_t launch_rx(const RxArgs &a, int fft_length, int mode, hipStream_t s) {
         return hipGetLastError();
       }
       const int grid = (a.nchan + 3) / 4;
-      if (a.q15) {  // the firmware's sample format either side (no taps: refused by the host)
+      if (a.q15 && debug) {  // ... with the side outputs / stage taps
+        if (a.agc) hipLaunchKernelGGL((rx512_kernel<kModeSam, true, 0, false, true, true>), dim3(grid), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((rx512_kernel<kModeSam, true, 0, false, false, true>), dim3(grid), dim3(256), 0, s, a);
+      } else if (a.q15) {  // the firmware's sample format either side
         if (a.agc) hipLaunchKernelGGL((rx512_kernel<kModeSam, false, 0, false, true, true>), dim3(grid), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((rx512_kernel<kModeSam, false, 0, false, false, true>), dim3(grid), dim3(256), 0, s, a);
       } else if (a.agc) {

@@ -40,7 +40,7 @@ def design_coeffs(params):
 
 
 BLOB_HEADER_WORDS = 32   # magic, abi, fft_length, mode, sizeof(params), 3 reserved | t41rx_params padded to 24 words
-STATE_HEADER_BYTES = 32  # checkpoint header: magic, abi, fft_length, n_channels, floats per channel, 3 reserved
+STATE_HEADER_BYTES = 32  # checkpoint header: magic, abi, fft_length, n_channels, floats per channel, sections, spectrumZoom, reserved
 
 
 def blob_params(blob):
@@ -136,7 +136,8 @@ class RxChain:
     def state_records(self, buf=None):
         """the per-channel records of a checkpoint (default: a fresh one) as float32 [n_channels, floats]"""
         buf = self.get_state() if buf is None else np.ascontiguousarray(buf, dtype=np.uint8)
-        return buf[STATE_HEADER_BYTES:].view(np.float32).reshape(self.n_channels, -1)
+        per = int(buf[:STATE_HEADER_BYTES].view(np.int32)[4])  # floats per channel of the path's section (the side stages' follow it)
+        return buf[STATE_HEADER_BYTES:STATE_HEADER_BYTES + 4 * per * self.n_channels].view(np.float32).reshape(self.n_channels, per)
 
     # -- the hot path ----------------------------------------------------------------------
     def ProcessIQData(self, float_buffer_L, float_buffer_R, out=None):

@@ -172,3 +172,42 @@ def test_gpu_display_spectrum_parity(built, zoom):
     assert e.value.status == _lib.ERR_ARG
     rx.set_display_spectrum(None, None)
     rx.ProcessIQData(dI[:, :4 * L].contiguous(), dQ[:, :4 * L].contiguous())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("zoom", [0, 3])
+def test_gpu_checkpoint_carries_the_display_memories(built, zoom):
+    """round 4: with the display spectrum on, a checkpoint carries the zoom filters' states, the sample ring
+    and FFT_spec_old (FFT.cpp:14-26): a restored stream draws the same spectra bit for bit; a checkpoint of another
+    spectrumZoom, or one with the section offered to a context whose display is off, is refused."""
+    import torch
+    import t41_sdr_amd as T
+    from t41_sdr_amd import _lib
+    nch, nfr = 4, 8
+    nco = siggen.nco_grid(nch, seed=61)
+    I, Q = siggen.make_iq(nch, nfr * L, nco, seed=62)
+    dI, dQ = torch.from_numpy(I).cuda(), torch.from_numpy(Q).cuda()
+    rx = T.RxChain(nch, T.default_params(), NCOFreq=nco)
+    spec, old = torch.zeros(nch, nfr, R, device="cuda"), torch.zeros(nch, nfr, R, device="cuda")
+    rx.set_display_spectrum(spec, old, zoom)
+    rx.ProcessIQData(dI, dQ)
+    whole = (spec.clone(), old.clone())
+    rx.reset()
+    cut = 3
+    rx.ProcessIQData(dI[:, :cut * L].contiguous(), dQ[:, :cut * L].contiguous())
+    ck = rx.get_state()
+    plain = T.RxChain(nch, T.default_params(), NCOFreq=nco)
+    assert ck.size == plain.get_state().size + 4 * nch * (64 + 1024 + 512)  # rx_internal.hpp: kDispFloats
+    rx.ProcessIQData(dI[:, :2 * L].contiguous(), dQ[:, :2 * L].contiguous())  # disturb
+    rx.set_state(ck)
+    rx.ProcessIQData(dI[:, cut * L:].contiguous(), dQ[:, cut * L:].contiguous())
+    n = nfr - cut  # (a call of n frames fills the buffers as [n_channels][n][512])
+    gs, go = spec.view(-1)[:nch * n * R].view(nch, n, R), old.view(-1)[:nch * n * R].view(nch, n, R)
+    assert torch.equal(gs, whole[0][:, cut:]) and torch.equal(go, whole[1][:, cut:])
+    with pytest.raises(T.T41RxError) as e:  # the display is off there: the section has no home
+        plain.set_state(ck)
+    assert e.value.status == _lib.ERR_STATE
+    rx.set_display_spectrum(spec, old, 1 if zoom != 1 else 2)
+    with pytest.raises(T.T41RxError) as e:
+        rx.set_state(ck)
+    assert e.value.status == _lib.ERR_STATE

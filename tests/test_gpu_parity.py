@@ -100,11 +100,20 @@ def test_parity_vs_golden_fixture(T, path):
         # the noise-reduction stages' own conditioning (tests/test_noise_reduction.py: measured on the oracle)
         assert np.isfinite(got).all()
         if kw.get("ANR_notchOn", 0):
-            return  # the notch from power-on adapts on the start-up transient: finite, not comparable
-        if kw["nrOptionSelect"] == 2:
-            assert (err < 1e-3).mean() > 0.97 and np.median(err) < 2e-5, err
-        else:
-            assert err.max() <= 1e-4, err
+            # The notch from power-on adapts on the front end's start-up transient, where it divides by the power of
+            # rounding-level samples: two f32 front ends that agree to 1e-7 leave it apart by what the ORACLE ITSELF
+            # moves by when its input is perturbed by one part in 1e7 (test_oracle_stage_conditioning).  That measured
+            # envelope is the tolerance here (round 3 stopped at isfinite): the HIP path must stay inside it.
+            rng = np.random.default_rng(2)
+            pI = (g["I"].astype(np.float64) * (1 + 1e-7 * rng.standard_normal(g["I"].shape))).astype(np.float32)
+            pQ = (g["Q"].astype(np.float64) * (1 + 1e-7 * rng.standard_normal(g["Q"].shape))).astype(np.float32)
+            env = siggen.block_rel_err(oracle_run(kw, g["nco"], pI, pQ), g["audio"], Lf)
+            assert env.max() > 1e-4  # (ill-conditioned indeed; otherwise this case belongs with the others)
+            assert err.max() <= 3.0 * env.max(), (err.max(), env.max())
+            return
+        # round 4: the spectral function's smoothing width is decided exactly as the scalar code decides it
+        # (nr_kernels.hip) -- its isolated 1e-3 .. 1e-2 frames are gone; Kim's measured error stays below 1e-5 here
+        assert err.max() <= (1e-4 if kw["nrOptionSelect"] == 2 else 2e-5), err
         return
     assert err.max() <= (AM_TOL if kw["mode"] == 2 else TOL), err
     if "spect" in g:

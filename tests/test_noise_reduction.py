@@ -240,10 +240,13 @@ NR_CASES = {
     "notch": (dict(ANR_notchOn=1), 3e-6, "max"),        # lane-per-channel, the reference's operations in its order: only the
     "lms": (dict(nrOptionSelect=3), 3e-6, "max"),       # interpolators' roundings differ
     "lms+notch": (dict(nrOptionSelect=3, ANR_notchOn=1), 3e-6, "max"),
-    "kim": (dict(nrOptionSelect=1), 1e-4, "max"),       # another FFT and summation order: the stage's conditioning (test above)
+    "kim": (dict(nrOptionSelect=1), 2e-5, "max"),       # another FFT and summation order (measured 6e-6; round 3 allowed 1e-4)
     "kim+notch": (dict(nrOptionSelect=1, ANR_notchOn=1), 2e-3, "max"),   # ... fed to the notch from power-on
-    "spectral": (dict(nrOptionSelect=2), 1e-3, "most"),
-    "spectral-am-agc": (dict(nrOptionSelect=2, mode=2, FLoCut=-3000, FHiCut=3000, AGCMode=2), 1e-3, "most"),
+    # round 4: the smoothing width NN is decided exactly as the scalar code decides it (sums redone in the reference's
+    # order next to its thresholds), so no frame takes another NN any more: every frame within 1e-4 (measured 3e-5),
+    # 97 % within 1e-5 (round 3: "98.5 % of the frames within 1e-3")
+    "spectral": (dict(nrOptionSelect=2), 1e-4, "most"),
+    "spectral-am-agc": (dict(nrOptionSelect=2, mode=2, FLoCut=-3000, FHiCut=3000, AGCMode=2), 1e-4, "most"),
 }
 
 
@@ -274,8 +277,8 @@ def test_gpu_stage_in_isolation(built, name):
     e = siggen.block_rel_err(got, want, L)
     if how == "max":
         assert e.max() <= tol, "worst %.3e at %s" % (e.max(), np.unravel_index(e.argmax(), e.shape))
-    else:  # discontinuous gain rule: nearly every frame, and the typical frame far below
-        assert (e < tol).mean() > 0.985 and np.median(e) < 2e-5, ((e < tol).mean(), np.median(e), e.max())
+    else:
+        assert e.max() <= tol and (e < 1e-5).mean() > 0.97 and np.median(e) < 5e-6, ((e < 1e-5).mean(), np.median(e), e.max())
 
 
 @pytest.mark.gpu
@@ -302,11 +305,10 @@ def test_gpu_whole_path_with_nr(built, name):
     b = rx.ProcessIQData(dI[:, 4 * L:].contiguous(), dQ[:, 4 * L:].contiguous()).cpu().numpy()
     rb = ob.process(I[:, 4 * L:], Q[:, 4 * L:])
     e = siggen.block_rel_err(np.concatenate([a, b], axis=1), np.concatenate([ra, rb], axis=1), L)
-    tol = {"notch-late": 5e-5, "lms": 1e-5, "kim": 1e-4}.get(name)
-    if tol is not None:
-        assert e.max() <= tol, e.max(axis=0)
-    else:
-        assert (e < 1e-3).mean() > 0.97 and np.median(e) < 2e-5, ((e < 1e-3).mean(), np.median(e))
+    tol = {"notch-late": 1e-5, "lms": 1e-5, "kim": 2e-5, "spectral": 1e-4}[name]  # (round 3: 5e-5, 1e-5, 1e-4, "97 % within 1e-3")
+    assert e.max() <= tol, e.max(axis=0)
+    if name == "spectral":
+        assert (e < 1e-5).mean() > 0.85 and np.median(e) < 5e-6, ((e < 1e-5).mean(), np.median(e))
 
 
 @pytest.mark.gpu
@@ -352,3 +354,70 @@ def test_gpu_nr_q15(built, kw):
                          torch.from_numpy(qQ.astype(np.float32) / np.float32(32768)).cuda()).cpu().numpy()
     want = np.clip(np.trunc(f.astype(np.float64) * 32768.0), -32768, 32767).astype(np.int16)
     assert np.array_equal(got, want) and np.abs(got).max() > 200
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(nrOptionSelect=1, ANR_notchOn=1), dict(nrOptionSelect=2), dict(nrOptionSelect=3, ANR_notchOn=1),
+                                dict(ANR_notchOn=1, AGCMode=2)], ids=["kim+notch", "spectral", "lms+notch", "notch-agc"])
+def test_gpu_checkpoint_carries_the_nr_memories(built, kw):
+    """round 4: a checkpoint taken with the stages running carries Xanr()'s taps / delay line /
+    leak words and the Kim / spectral statistics (Noise.cpp:19-56): a stream restored from it -- in the same context or in
+    a fresh one -- continues bit for bit like the uninterrupted stream; restoring a checkpoint WITHOUT the section (taken
+    before the stages first ran) puts them back to power-on, not to whatever the replaced stream left."""
+    import torch
+    import t41_sdr_amd as T
+    nch, nfr = 11, 16
+    nco = siggen.nco_grid(nch, seed=8)
+    I, Q = siggen.make_iq(nch, nfr * L, nco, mode=0, seed=80)
+    dI, dQ = torch.from_numpy(I).cuda(), torch.from_numpy(Q).cuda()
+    cut = 7
+    rx = T.RxChain(nch, T.default_params(**kw), NCOFreq=nco)
+    fresh = rx.get_state()  # before the stages ever ran: no section
+    whole = rx.ProcessIQData(dI, dQ).cpu().numpy()
+    rx.reset()
+    a = rx.ProcessIQData(dI[:, :cut * L].contiguous(), dQ[:, :cut * L].contiguous()).cpu().numpy()
+    ck = rx.get_state()
+    assert ck.size > fresh.size  # the noise-reduction section is there now
+    rx.ProcessIQData(dI[:, :3 * L].contiguous(), dQ[:, :3 * L].contiguous())  # disturb every memory
+    rx.set_state(ck)
+    b = rx.ProcessIQData(dI[:, cut * L:].contiguous(), dQ[:, cut * L:].contiguous()).cpu().numpy()
+    assert np.array_equal(np.concatenate([a, b], axis=1), whole)
+    # into a fresh context (its stage memories are not even allocated yet)
+    ry = T.RxChain(nch, T.default_params(**kw), NCOFreq=nco)
+    ry.set_state(ck)
+    b2 = ry.ProcessIQData(dI[:, cut * L:].contiguous(), dQ[:, cut * L:].contiguous()).cpu().numpy()
+    assert np.array_equal(b2, b)
+    assert np.array_equal(ry.get_state(), rx.get_state())
+    # a section-less checkpoint = power-on for the stages as well
+    rx.set_state(fresh)
+    again = rx.ProcessIQData(dI, dQ).cpu().numpy()
+    assert np.array_equal(again, whole)
+    # a damaged section is refused and changes nothing
+    bad = ck.copy()
+    sec = bad[T.rx.STATE_HEADER_BYTES + rx.state_records(ck).nbytes:].view(np.float32)
+    sec[(64 + 79) * nch + 3] = np.float32(1e9)  # ANR_lidx of channel 3 (nr_kernels.hpp: kAnrStLidx)
+    with pytest.raises(T.T41RxError):
+        rx.set_state(bad)
+
+
+@pytest.mark.gpu
+def test_gpu_live_switch_spectral_to_kim_matches_the_oracle(built):
+    """SpectralNoiseReduction() leaves NR_X[.][0] behind every frame (Noise.cpp:488) and Kim1_NR()'s
+    three-frame average (Noise.cpp:214-218) starts from it after a live switch of nrOptionSelect from 2 to 1"""
+    import torch
+    import t41_sdr_amd as T
+    nch = 8
+    nco = siggen.nco_grid(nch, seed=10)
+    I, Q = siggen.make_iq(nch, 24 * L, nco, mode=0, seed=100)
+    dI, dQ = torch.from_numpy(I).cuda(), torch.from_numpy(Q).cuda()
+    kw = dict(nrOptionSelect=2)
+    rx = T.RxChain(nch, T.default_params(**kw), NCOFreq=nco)
+    ob = O.OracleBatch(O.default_params(**kw), np.asarray(nco, np.int32))
+    rx.ProcessIQData(dI[:, :8 * L].contiguous(), dQ[:, :8 * L].contiguous())  # (spectral still initialising: audio untouched)
+    ob.process(I[:, :8 * L], Q[:, :8 * L])
+    rx.CalcFilters(nrOptionSelect=1)
+    ob.p.nrOptionSelect = 1
+    got = rx.ProcessIQData(dI[:, 8 * L:].contiguous(), dQ[:, 8 * L:].contiguous()).cpu().numpy()
+    ref = ob.process(I[:, 8 * L:], Q[:, 8 * L:])
+    e = siggen.block_rel_err(got, ref, L)
+    assert e.max() <= 1e-4, e.max(axis=0)  # Kim's tolerance (its conditioning), from the first frame after the switch

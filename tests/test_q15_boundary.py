@@ -131,8 +131,59 @@ def test_gpu_q15_argument_errors(built):
     x = torch.zeros(4, L, dtype=torch.int16, device="cuda")
     with pytest.raises(ValueError):
         rx.ProcessIQData_q15(x.float(), x.float())
+    # (round 4: the stage taps and side outputs work on the q15 entry points -- test_gpu_q15_side_outputs_and_taps;
+    #  what stays refused is a call longer than the tap buffers were sized for)
     tap = torch.zeros(4 * 256, device="cuda")
     rx.set_debug_taps(None, None, tap)
+    rx.ProcessIQData_q15(x, x)
+    x2 = torch.zeros(4, 2 * L, dtype=torch.int16, device="cuda")
     with pytest.raises(T.T41RxError) as e:
-        rx.ProcessIQData_q15(x, x)
-    assert e.value.status == _lib.ERR_UNSUPPORTED
+        rx.ProcessIQData_q15(x2, x2)
+    assert e.value.status == _lib.ERR_ARG
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(mode=0), dict(mode=0, AGCMode=1), dict(mode=2, FLoCut=-3000, FHiCut=3000), dict(mode=3),
+                                dict(mode=8, FLoCut=-3000, FHiCut=3000, AGCMode=2)], ids=["usb", "usb-agc", "am", "nfm", "sam-agc"])
+def test_gpu_q15_side_outputs_and_taps(built, kw):
+    """the reference computes its display FFT and audio spectrum inside every ProcessIQData() call on
+    the q15-fed buffers (Process.cpp:107-108 -> :184-186, :211-215, :550-570).  On the q15 entry points the display
+    spectrum (zoom 0 and 2), the audio spectrum / S-meter words and the three stage taps must be bit for bit what the f32
+    entry point gives on the converted samples (arm_q15_to_float is exact), over two calls (the side stages' memories
+    carry over), and the audio must be that call's audio through arm_float_to_q15."""
+    import torch
+    import t41_sdr_amd as T
+    nch, nfr = 7, 3
+    nco = siggen.nco_grid(nch, seed=31)
+    I, Q = siggen.make_iq(nch, 2 * nfr * L, nco, mode=min(kw["mode"], 2) if kw["mode"] != 3 else 3, seed=32)
+    qI = np.clip(np.round(I * 32768.0), -32768, 32767).astype(np.int16)
+    qQ = np.clip(np.round(Q * 32768.0), -32768, 32767).astype(np.int16)
+    fI, fQ = qI.astype(np.float32) / np.float32(32768), qQ.astype(np.float32) / np.float32(32768)
+    kw = dict(kw, audioVolume=60)
+    for zoom in (0, 2):
+        outs = []
+        for q15 in (False, True):
+            rx = T.RxChain(nch, T.default_params(**kw), NCOFreq=nco)
+            spec, old = torch.zeros(nch, nfr, 512, device="cuda"), torch.zeros(nch, nfr, 512, device="cuda")
+            asp, amx = torch.zeros(nch, nfr, 1024, device="cuda"), torch.zeros(nch, nfr, 3, device="cuda")
+            t_nco, t_dec, t_dem = (torch.zeros(nch, nfr * 2 * L, device="cuda"), torch.zeros(nch, nfr * 512, device="cuda"),
+                                   torch.zeros(nch, nfr * 256, device="cuda"))
+            rx.set_display_spectrum(spec, old, zoom)
+            rx.set_audio_spectrum(asp, amx)
+            rx.set_debug_taps(t_nco, t_dec, t_dem)
+            got = []
+            for c in range(2):
+                sl = slice(c * nfr * L, (c + 1) * nfr * L)
+                if q15:
+                    a = rx.ProcessIQData_q15(torch.from_numpy(qQ[:, sl].copy()).cuda(), torch.from_numpy(qI[:, sl].copy()).cuda())
+                else:
+                    a = rx.ProcessIQData(torch.from_numpy(fI[:, sl].copy()).cuda(), torch.from_numpy(fQ[:, sl].copy()).cuda())
+                got.append([t.clone() for t in (a, spec, old, asp, amx, t_nco, t_dec, t_dem)])
+            outs.append(got)
+        for c in range(2):
+            f32, q = outs[0][c], outs[1][c]
+            want = torch.clamp(torch.trunc(f32[0].double() * 32768.0), -32768, 32767).to(torch.int16)
+            assert torch.equal(q[0], want), (zoom, c, "audio")
+            for k, name in enumerate(("FFT_spec", "FFT_spec_old", "audioSpectBuffer", "audioMax", "post_nco", "dec", "demod"), start=1):
+                assert torch.equal(q[k], f32[k]), (zoom, c, name)
+            assert float(q[1].abs().max()) > 0 and float(q[3].abs().max()) > 0

@@ -32,58 +32,104 @@
 namespace t41 {
 
 // ------------------------------------------------------------------------------------------
-// Xanr(), one lane per channel
+// Xanr(): 16 channels per wave, a channel's 64 taps on the four lanes (c, c + 16, c + 32, c + 48)
 // ------------------------------------------------------------------------------------------
-constexpr int kAnrRow = 65;                    // LDS row pitch in floats (64 channels + 1)
+// Round 3 ran one lane per channel (64 taps in 64 registers): a sample's step was ~430 instructions, 300 of them the
+// products, squares and the taps' update -- independent work that one wave had to issue between the 64 additions of the
+// filter's output, which the reference accumulates in tap order and which therefore stay a chain.  Round 4 spreads that
+// work over the wave: lane (g, c) = 16 g + c holds 16 taps of channel c, so products / update are 8 packed
+// instructions per lane instead of 32, and the chain walks through the four lane groups in tap order: every lane adds
+// its 16 products to whatever partial sum it holds, the partial sum that matters sits in the "active" group, and after
+// 16 additions it moves on to the next group by ONE lane-swap instruction (v_permlane16_swap / v_permlane32_swap; the
+// groups are visited in the order 0, 1, 3, 2 because those are the moves the two instructions make).  Same additions,
+// same order, same roundings as the scalar loop; a sample costs the chain's 64 dependent additions and little else.
+constexpr int kAnrCw = 16;                     // channels per wave / workgroup
+constexpr int kAnrRow = kAnrCw + 1;            // LDS row pitch in floats (odd: the transposing stage-in / stage-out and the window reads are conflict-free)
 constexpr int kAnrTile = kAnrHist + 256;       // rows of the input tile: 79 of history + the frame
-constexpr size_t kAnrLdsBytes = ((size_t)(kAnrTile + 256) * kAnrRow + 3 + 512) * sizeof(float);  // input tile + output tile + two slots of 64 x (sigma, 1 / sigma', 1 - 2 mu sigma / sigma' as a double)
+constexpr int kAnrSigOff = ((kAnrTile + 256) * kAnrRow + 3) & ~3;
+constexpr size_t kAnrLdsBytes = ((size_t)kAnrSigOff + 2 * kAnrCw * 4) * sizeof(float);  // input tile + output tile + two slots of 16 x (sigma, 1 / sigma', 1 - 2 mu sigma / sigma' as a double)
 
-// One pass of Noise.cpp:331-369 over the 256 samples in T[kAnrHist ..], split over the workgroup's TWO waves (lane =
-// channel in both): a sample's step is ~430 instructions for one wave, most of them the two sums over the 64-tap
-// window, each a dependent chain in tap order.  Wave 1 takes the window's sum of squares (ANR_sigma), wave 0 the
-// filter output, the error, the leak logic and the taps' update; sigma crosses through LDS (two slots: wave 1 may
-// be a sample ahead) behind ONE workgroup barrier per sample.  Every value by the same operations in the same order
-// as the scalar loop.
-// O (may be null): output tile; SIG: [2][64] float4.
+// first tap of lane group g: the chain visits the groups in the order 0, 1, 3, 2
+__device__ __forceinline__ int anr_tap_base(int g) { return 16 * ((g == 2) ? 3 : (g == 3) ? 2 : g); }
+// the partial sum moves from the group that has just finished to the one that continues (every other lane: don't care)
+template <int PHASE>
+__device__ __forceinline__ float anr_hand_on(float y) {
+  float a = y, b = y;
+  if (PHASE == 0) {        // group 0 -> group 1
+    lane_swap16(a, b);
+    return a;
+  } else if (PHASE == 1) { // group 1 -> group 3
+    lane_swap32(a, b);
+    return a;
+  } else {                 // group 3 -> group 2
+    lane_swap16(a, b);
+    return b;
+  }
+}
+// group 2's value to every group
+__device__ __forceinline__ float anr_from_group2(float y) {
+  float a = y, b = y;
+  lane_swap32(a, b);  // b = {y2, y3, y2, y3}
+  float c = b, d = b;
+  lane_swap16(c, d);  // c = {y2, y2, y2, y2}
+  return c;
+}
+// sum of p[0 .. 15] in tap order on top of the running sum, through the four groups: the reference's 64 additions
+__device__ __forceinline__ float anr_chain(const f2 (&p)[8]) {
+#pragma clang fp contract(off)
+  float y = 0;
+#pragma unroll
+  for (int ph = 0; ph < 4; ++ph) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      y += p[t].y;
+      y += p[t].x;
+    }
+    if (ph == 0) y = anr_hand_on<0>(y);
+    else if (ph == 1) y = anr_hand_on<1>(y);
+    else if (ph == 2) y = anr_hand_on<2>(y);
+  }
+  return y;  // valid in group 2
+}
+
+// One pass of Noise.cpp:331-369 over the 256 samples in T[kAnrHist ..], split over the workgroup's TWO waves (same
+// lane -> (group, channel) map in both): wave 1 takes the window's sum of squares (ANR_sigma) and what depends on it
+// alone (an IEEE double division), wave 0 the filter output, the error, the leak logic and the taps' update; sigma
+// crosses through LDS (two slots: wave 1 may be a sample ahead) behind ONE workgroup barrier per sample.  Every value
+// by the same operations in the same order as the scalar loop.
+// O (may be null): output tile; SIG: [2][16] float4.
 template <bool NOTCH>
-__device__ __forceinline__ void anr_pass_y(const float *T, float *O, const float *SIG, f2 (&w)[kAnrTaps / 2], float &lidx, float &ngamma, int lane) {
+__device__ __forceinline__ void anr_pass_y(const float *T, float *O, const float *SIG, f2 (&w)[8], float &lidx, float &ngamma, int lane) {
 #pragma clang fp contract(off)
   const float ANR_den_mult = 6.25e-10, ANR_gamma = 0.1, ANR_lidx_min = 120.0, ANR_lidx_max = 200.0;
   const float ANR_lincr = 1.0, ANR_ldecr = 3.0, ANR_two_mu = 0.0001;
-  // The taps' update of sample i (96 independent instructions) is fused, pair by pair, into the dot product of sample
-  // i + 1 (a chain of 64 dependent additions whose latency it fills): tap pair j is updated, then used.  Same values
-  // as updating all taps first.  Two window register sets alternate (the loop is unrolled by two).
+  const int c = lane & 15, g = lane >> 4, tb = anr_tap_base(g);
+  // The taps' update of sample i is fused into the products of sample i + 1 (it needs sample i's window, which dp still
+  // holds): tap pair t is updated, then used.  Same values as updating all taps first.
   float c0 = 1.0f, c1 = 0.0f;  // pending update of the previous sample (none yet: w * 1 + 0 * d would not be exact for
   bool pending = false;        // -0 / NaN taps, so it is skipped rather than applied)
-  // Two window register sets alternate (the loop is unrolled by two): dj receives this sample's window -- all of it
-  // requested BEFORE the chain starts, one LDS round trip exposed per sample instead of one per pair (measured:
-  // 258 -> 214 us per frame; requesting the next sample's window a step ahead instead is slower: more than 15 LDS reads
-  // in flight make the wait for sigma wait for them too) --, dp still holds the previous sample's for the fused update.
-  auto step = [&](int i, f2 (&dj)[kAnrTaps / 2], const f2 (&dp)[kAnrTaps / 2]) {
-    const float *row = T + i * kAnrRow + lane;
+  auto step = [&](int i, f2 (&dj)[8], const f2 (&dp)[8]) {
+    const float *row = T + i * kAnrRow + c;
     const float d_in = row[kAnrHist * kAnrRow];  // ANR_d[ANR_in_idx]
     // A register pair holds taps (j + 1, j) in (.x, .y): the window's rows ascend in time, i.e. descend in j, so one
-    // ds_read2_b32 fills a pair without a move.
+    // ds_read2_b32 fills a pair without a move.  (idx = in_idx + j + ANR_delay: the sample written j + 16 steps ago)
 #pragma unroll
-    for (int j = 0; j < kAnrTaps; j += 2)  // idx = in_idx + j + ANR_delay: the sample written j + 16 steps ago
-      dj[j / 2] = f2{row[(kAnrTaps - 2 - j) * kAnrRow], row[(kAnrTaps - 1 - j) * kAnrRow]};
-    __builtin_amdgcn_sched_barrier(0);
-    // (two taps per multiply instruction -- v_pk_mul_f32 rounds each product exactly like the scalar multiply -- and the
-    // sum accumulated one product at a time in tap order: the reference's roundings, fewer instructions)
-    float y = 0;
+    for (int t = 0; t < 16; t += 2)
+      dj[t / 2] = f2{row[(kAnrTaps - 2 - tb - t) * kAnrRow], row[(kAnrTaps - 1 - tb - t) * kAnrRow]};
+    // (two taps per multiply instruction -- v_pk_mul_f32 rounds each product exactly like the scalar multiply)
+    f2 p[8];
 #pragma unroll
-    for (int j = 0; j < kAnrTaps; j += 2) {
-      if (pending) w[j / 2] = splat(c0) * w[j / 2] + splat(c1) * dp[j / 2];
-      const f2 p = w[j / 2] * dj[j / 2];
-      y += p.y;
-      y += p.x;
+    for (int t = 0; t < 8; ++t) {
+      if (pending) w[t] = splat(c0) * w[t] + splat(c1) * dp[t];
+      p[t] = w[t] * dj[t];
     }
-    __syncthreads();  // wave 1's sigma of this sample is in its slot, with what depends on sigma alone (an IEEE double division)
-    const float4 sg = *reinterpret_cast<const float4 *>(SIG + 4 * (64 * (i & 1) + lane));
+    const float y = anr_from_group2(anr_chain(p));
+    __syncthreads();  // wave 1's sigma of this sample is in its slot, with what depends on sigma alone
+    const float4 sg = *reinterpret_cast<const float4 *>(SIG + 4 * (kAnrCw * (i & 1) + c));
     const float sigma = sg.x, inv_sigp = sg.y;  // inv_sigp = (float)(1.0 / ((double)sigma + 1e-10))
     const double one_m = __hiloint2double(__float_as_int(sg.w), __float_as_int(sg.z));  // 1.0 - (double)(ANR_two_mu * sigma * inv_sigp)
     const float error = d_in - y;
-    if (O) O[i * kAnrRow + lane] = NOTCH ? error : y;
+    if (O && g == 0) O[i * kAnrRow + c] = NOTCH ? error : y;
     float nel = (float)((double)error * one_m);
     if (nel < 0.0f) nel = -nel;
     float nev = (float)((double)d_in - (1.0 - (double)(ANR_two_mu * ngamma)) * (double)y - (double)(ANR_two_mu * error * sigma * inv_sigp));
@@ -102,34 +148,35 @@ __device__ __forceinline__ void anr_pass_y(const float *T, float *O, const float
     c1 = ANR_two_mu * error * inv_sigp;
     pending = true;
   };
-  f2 da[kAnrTaps / 2], db[kAnrTaps / 2];
+  f2 da[8], db[8];
 #pragma unroll
-  for (int j = 0; j < kAnrTaps / 2; ++j) db[j] = splat(0.0f);
+  for (int t = 0; t < 8; ++t) db[t] = splat(0.0f);
   for (int i = 0; i < 256; i += 2) {
     step(i, da, db);
     step(i + 1, db, da);
   }
   // the last sample's update (its window is in db)
 #pragma unroll
-  for (int j = 0; j < kAnrTaps / 2; ++j) w[j] = splat(c0) * w[j] + splat(c1) * db[j];
+  for (int t = 0; t < 8; ++t) w[t] = splat(c0) * w[t] + splat(c1) * db[t];
 }
 __device__ __forceinline__ void anr_pass_sigma(const float *T, float *SIG, int lane) {
 #pragma clang fp contract(off)
+  const int c = lane & 15, g = lane >> 4, tb = anr_tap_base(g);
   for (int i = 0; i < 256; ++i) {
-    const float *row = T + i * kAnrRow + lane;
-    float sigma = 0;
+    const float *row = T + i * kAnrRow + c;
+    f2 q[8];
 #pragma unroll
-    for (int j = 0; j < kAnrTaps; j += 2) {
-      const f2 d = f2{row[(kAnrTaps - 2 - j) * kAnrRow], row[(kAnrTaps - 1 - j) * kAnrRow]};
-      const f2 q = d * d;
-      sigma += q.y;
-      sigma += q.x;
+    for (int t = 0; t < 16; t += 2) {
+      const f2 d = f2{row[(kAnrTaps - 2 - tb - t) * kAnrRow], row[(kAnrTaps - 1 - tb - t) * kAnrRow]};
+      q[t / 2] = d * d;
     }
+    const float sigma = anr_chain(q);  // (group 2 holds it)
     const float ANR_two_mu = 0.0001;
     const float inv_sigp = (float)(1.0 / ((double)sigma + 1e-10));
     const double one_m = 1.0 - (double)(ANR_two_mu * sigma * inv_sigp);
-    *reinterpret_cast<float4 *>(SIG + 4 * (64 * (i & 1) + lane)) =
-        make_float4(sigma, inv_sigp, __int_as_float(__double2loint(one_m)), __int_as_float(__double2hiint(one_m)));
+    if (g == 2)
+      *reinterpret_cast<float4 *>(SIG + 4 * (kAnrCw * (i & 1) + c)) =
+          make_float4(sigma, inv_sigp, __int_as_float(__double2loint(one_m)), __int_as_float(__double2hiint(one_m)));
     __syncthreads();
   }
 }
@@ -137,33 +184,35 @@ __device__ __forceinline__ void anr_pass_sigma(const float *T, float *SIG, int l
 __global__ __launch_bounds__(128, 1) void anr_kernel(const NrArgs a) {
 #pragma clang fp contract(off)
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float *T = sm, *O = sm + kAnrTile * kAnrRow, *SIG = sm + (((kAnrTile + 256) * kAnrRow + 3) & ~3);  // (16-byte aligned)
+  float *T = sm, *O = sm + kAnrTile * kAnrRow, *SIG = sm + kAnrSigOff;  // (16-byte aligned)
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // 0: filter output and update, 1: sum of squares
-  const int ch0 = blockIdx.x * 64;
-  const int nlive = (a.nchan - ch0 < 64) ? a.nchan - ch0 : 64;
-  const int ch = ch0 + (lane < nlive ? lane : nlive - 1);  // dead lanes shadow the last live channel (their stores are skipped)
+  const int c = lane & 15, g = lane >> 4, tb = anr_tap_base(g);
+  const int ch0 = blockIdx.x * kAnrCw;
+  const int nlive = (a.nchan - ch0 < kAnrCw) ? a.nchan - ch0 : kAnrCw;
+  const int ch = ch0 + (c < nlive ? c : nlive - 1);  // dead lanes shadow the last live channel (their stores are skipped)
   const size_t nch = (size_t)a.nchan;
-  f2 w[kAnrTaps / 2];  // ANR_w (wave 0), two taps per register pair: (.x, .y) = taps (2 j + 1, 2 j), see anr_pass_y
+  f2 w[8];  // ANR_w (wave 0): this lane's 16 taps, two per register pair: (.x, .y) = taps (tb + 2 t + 1, tb + 2 t)
   float lidx = 0, ngamma = 0;
   if (wv == 0) {
 #pragma unroll
-    for (int j = 0; j < kAnrTaps / 2; ++j) w[j] = f2{a.anr[(size_t)(kAnrStW + 2 * j + 1) * nch + ch], a.anr[(size_t)(kAnrStW + 2 * j) * nch + ch]};
-    for (int r = 0; r < kAnrHist; ++r) T[r * kAnrRow + lane] = a.anr[(size_t)(kAnrStHist + r) * nch + ch];
+    for (int t = 0; t < 8; ++t)
+      w[t] = f2{a.anr[(size_t)(kAnrStW + tb + 2 * t + 1) * nch + ch], a.anr[(size_t)(kAnrStW + tb + 2 * t) * nch + ch]};
+    for (int r = g; r < kAnrHist; r += 4) T[r * kAnrRow + c] = a.anr[(size_t)(kAnrStHist + r) * nch + ch];
     lidx = a.anr[(size_t)kAnrStLidx * nch + ch], ngamma = a.anr[(size_t)kAnrStNgamma * nch + ch];
   }
   for (int f = 0; f < a.nframes; ++f) {
-    // stage the frame in: row c of the scratch = channel ch0 + c, 256 consecutive samples, 4 x 256 B per row (the two
-    // waves take alternate channels)
+    // stage the frame in: column cc of the tile = channel ch0 + cc, 256 consecutive samples, 4 x 256 B per channel (the
+    // two waves take alternate channels)
     __syncthreads();
-    for (int c = wv; c < nlive; c += 2) {
-      const float *src = a.aud + ((size_t)(ch0 + c) * a.nframes + f) * 256;
+    for (int cc = wv; cc < nlive; cc += 2) {
+      const float *src = a.aud + ((size_t)(ch0 + cc) * a.nframes + f) * 256;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) T[(kAnrHist + lane + 64 * q) * kAnrRow + c] = src[lane + 64 * q];
+      for (int q = 0; q < 4; ++q) T[(kAnrHist + lane + 64 * q) * kAnrRow + cc] = src[lane + 64 * q];
     }
-    for (int c = nlive + ((nlive ^ wv) & 1); c < 64; c += 2) {
+    for (int cc = nlive + ((nlive ^ wv) & 1); cc < kAnrCw; cc += 2) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) T[(kAnrHist + lane + 64 * q) * kAnrRow + c] = 0.0f;
+      for (int q = 0; q < 4; ++q) T[(kAnrHist + lane + 64 * q) * kAnrRow + cc] = 0.0f;
     }
     __syncthreads();
     if (a.nr_option == 3) {  // Process.cpp:852-857: Xanr() as noise reduction; its result stays in float_buffer_R, float_buffer_L is scaled by 1.5
@@ -173,10 +222,11 @@ __global__ __launch_bounds__(128, 1) void anr_kernel(const NrArgs a) {
       if (wv == 0) {
         if (a.notch) {
           // the notch pass sees the scaled block behind the unscaled one: its delay line = the last 79 unscaled samples
-          for (int r = 0; r < kAnrHist; ++r) T[r * kAnrRow + lane] = T[(256 + r) * kAnrRow + lane];
-          for (int i = 0; i < 256; ++i) T[(kAnrHist + i) * kAnrRow + lane] = T[(kAnrHist + i) * kAnrRow + lane] * 1.5f;
+          for (int r = g; r < kAnrHist; r += 4) T[r * kAnrRow + c] = T[(256 + r) * kAnrRow + c];
+          __builtin_amdgcn_wave_barrier();
+          for (int i = g; i < 256; i += 4) T[(kAnrHist + i) * kAnrRow + c] = T[(kAnrHist + i) * kAnrRow + c] * 1.5f;
         } else {
-          for (int i = 0; i < 256; ++i) O[i * kAnrRow + lane] = T[(kAnrHist + i) * kAnrRow + lane] * 1.5f;
+          for (int i = g; i < 256; i += 4) O[i * kAnrRow + c] = T[(kAnrHist + i) * kAnrRow + c] * 1.5f;
         }
       }
       __syncthreads();
@@ -188,23 +238,25 @@ __global__ __launch_bounds__(128, 1) void anr_kernel(const NrArgs a) {
     }
     // the delay line's live part for the next block
     if (wv == 0)
-      for (int r = 0; r < kAnrHist; ++r) T[r * kAnrRow + lane] = T[(256 + r) * kAnrRow + lane];
+      for (int r = g; r < kAnrHist; r += 4) T[r * kAnrRow + c] = T[(256 + r) * kAnrRow + c];
     __syncthreads();
-    for (int c = wv; c < nlive; c += 2) {
-      float *dst = a.aud + ((size_t)(ch0 + c) * a.nframes + f) * 256;
+    for (int cc = wv; cc < nlive; cc += 2) {
+      float *dst = a.aud + ((size_t)(ch0 + cc) * a.nframes + f) * 256;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) dst[lane + 64 * q] = O[(lane + 64 * q) * kAnrRow + c];
+      for (int q = 0; q < 4; ++q) dst[lane + 64 * q] = O[(lane + 64 * q) * kAnrRow + cc];
     }
   }
-  if (wv == 0 && lane < nlive) {
+  if (wv == 0 && c < nlive) {
 #pragma unroll
-    for (int j = 0; j < kAnrTaps / 2; ++j) {
-      a.anr[(size_t)(kAnrStW + 2 * j + 1) * nch + ch] = w[j].x;
-      a.anr[(size_t)(kAnrStW + 2 * j) * nch + ch] = w[j].y;
+    for (int t = 0; t < 8; ++t) {
+      a.anr[(size_t)(kAnrStW + tb + 2 * t + 1) * nch + ch] = w[t].x;
+      a.anr[(size_t)(kAnrStW + tb + 2 * t) * nch + ch] = w[t].y;
     }
-    for (int r = 0; r < kAnrHist; ++r) a.anr[(size_t)(kAnrStHist + r) * nch + ch] = T[r * kAnrRow + lane];
-    a.anr[(size_t)kAnrStLidx * nch + ch] = lidx;
-    a.anr[(size_t)kAnrStNgamma * nch + ch] = ngamma;
+    for (int r = g; r < kAnrHist; r += 4) a.anr[(size_t)(kAnrStHist + r) * nch + ch] = T[r * kAnrRow + c];
+    if (g == 0) {
+      a.anr[(size_t)kAnrStLidx * nch + ch] = lidx;
+      a.anr[(size_t)kAnrStNgamma * nch + ch] = ngamma;
+    }
   }
 }
 
@@ -634,7 +686,7 @@ hipError_t launch_nr(const NrArgs &a, hipStream_t s) {
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&anr_kernel),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAnrLdsBytes);
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL(anr_kernel, dim3((a.nchan + 63) / 64), dim3(128), kAnrLdsBytes, s, a);
+    hipLaunchKernelGGL(anr_kernel, dim3((a.nchan + kAnrCw - 1) / kAnrCw), dim3(128), kAnrLdsBytes, s, a);
     e = hipGetLastError();
   }
   return e;

@@ -424,8 +424,25 @@ __device__ __forceinline__ void load_taps(float (&dst)[N], CFloatPtr p) {
 // values are consumed right after their load, taps arrive in 8-wide scalar-load chunks just
 // before first use, and the accumulators are pinned every GROUP loads so the compiler cannot
 // hoist the whole window into registers.
+// one tap on a complex sample: ONE v_pk_fma_f32 (tap broadcast by op_sel), or -- T41RX_FIR_PLAIN, an experiment: is the
+// packed form the cheaper one for a chip that holds its clock down under this kernel? -- two v_fma_f32 (same roundings)
+#ifndef T41RX_FIR_PLAIN
+#define T41RX_FIR_PLAIN 0
+#endif
+__device__ __forceinline__ cf fir_mac(float tap, cf x, cf acc) {
+#if T41RX_FIR_PLAIN
+  cf r;
+  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r.x) : "s"(tap), "v"(x.x), "v"(acc.x));
+  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r.y) : "s"(tap), "v"(x.y), "v"(acc.y));
+  return r;
+#else
+  return pk_fma(splat(tap), x, acc);
+#endif
+}
+// (T41RX_LOO 13 / 14, timing experiments: the /2 / the /4 decimator's window taken from registers `regsrc` instead of
+// LDS -- the arithmetic kept, the LDS reads gone: what would a decimator that needs no window reads be worth?)
 template <int NT, int OFF0, int OFF1, int NLOAD, int GROUP, typename IDX>
-__device__ __forceinline__ void fir_pair(const float *win, IDX idx, CFloatPtr taps, cf &acc0, cf &acc1) {
+__device__ __forceinline__ void fir_pair(const float *win, IDX idx, CFloatPtr taps, cf &acc0, cf &acc1, const cf *regsrc = nullptr) {
   constexpr int NTP = (NT + 7) & ~7;
   float tc[NTP];
   acc0 = splat(0.0f);
@@ -433,7 +450,9 @@ __device__ __forceinline__ void fir_pair(const float *win, IDX idx, CFloatPtr ta
 #pragma unroll
   for (int l = 0; l < NLOAD; ++l) {
     if (l > 0 && (l % GROUP) == 0) asm volatile("" : "+v"(acc0), "+v"(acc1)::"memory");
-    const float4 t = lds4(win + 2 * idx(2 * l));
+    float4 t;
+    if (regsrc) t = make_float4(regsrc[(2 * l) & 7].x, regsrc[(2 * l) & 7].y, regsrc[(2 * l + 1) & 7].x, regsrc[(2 * l + 1) & 7].y);
+    else t = lds4(win + 2 * idx(2 * l));
     const cf tv[2] = {cf{t.x, t.y}, cf{t.z, t.w}};
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -446,9 +465,9 @@ __device__ __forceinline__ void fir_pair(const float *win, IDX idx, CFloatPtr ta
 #pragma unroll
           for (int q = 0; q < 8; ++q) tc[i0 + q] = chunk[q];
         }
-        acc0 = pk_fma(splat(tc[i0]), tv[j], acc0);
+        acc0 = fir_mac(tc[i0], tv[j], acc0);
       }
-      if (i1 >= 0 && i1 < NT) acc1 = pk_fma(splat(tc[i1]), tv[j], acc1);
+      if (i1 >= 0 && i1 < NT) acc1 = fir_mac(tc[i1], tv[j], acc1);
     }
   }
 }
@@ -607,6 +626,13 @@ __device__ __forceinline__ void agc_slow_block(AgcState &st, const AgcConsts &g,
   st = AgcState{fast_backaverage, hang_backaverage, volts, save_volts, state, decay_type, hang_counter};
 }
 
+// State 3's decay step inside the fast block: 1 = the reference's double-precision expression (shipped); 0 = two FMAs
+// that bracket it + the slow block where they differ (round 4 experiment: bit-identical over tools/agc_decay_check.py's
+// 24 streams, and no faster -- 32.2-32.4 against 31.9-32.1 us per frame on bench.py's ssb_agc, 36.3 against 33.5 on pure
+// noise, where one block in ten then takes the slow path: the chain is paced by more than this step)
+#ifndef T41RX_AGC_DECAY64
+#define T41RX_AGC_DECAY64 1
+#endif
 // Lane masks as plain 64-bit scalars.  Written out by hand because the compiler, given bools,
 // rebuilds them as 0/1 integers in VGPRs every time two of them meet in a select: with these
 // three wrappers a comparison is one VALU instruction with an SGPR-pair result, the logic between
@@ -684,8 +710,26 @@ __device__ __forceinline__ lanemask agc_fast_block(AgcState &st, AgcLane &d, con
     const float step = (ring_max - volts) * pick(ge, attack_mult, d.stay);
     float next = volts + step;
     if (HAS3) {
+#if T41RX_AGC_DECAY64
       const float next3 = (float)((double)volts + (double)step * .05);
       next = pick(d.is3 & ~ge, next3, next);
+#else
+      // State 3's decay step, (float)((double)volts + (double)step * .05) (DSP_Fn.cpp:614): four dependent double-precision
+      // instructions (two conversions in, a multiply, an add, a conversion out) in a chain that is paced by its
+      // instruction count.  Sandwich instead: for floats c_lo < .05 < c_hi the products step * c are exact in double, the
+      // double sum and both roundings are monotonic, so the reference's value lies between fl(volts + step * c_lo) and
+      // fl(volts + step * c_hi) -- two FMAs.  Where the two agree that IS the reference's value; where they differ (a
+      // rounding boundary between them: about |step| / |volts| / 10 of the steps, i.e. < 1e-4) the block is redone by
+      // agc_slow_block(), which has the expression as written.  c_lo / c_hi are the SECOND neighbours of .05 either side:
+      // an FMA rounds once where the reference rounds to double first, which can move the result by one ulp when the sum
+      // sits within 2^-53 of a boundary -- a shift 10^7 times smaller than the one the extra neighbour adds.
+      const float r_lo = __builtin_fmaf(step, __uint_as_float(0x3d4ccccbu), volts);
+      const float next3 = __builtin_fmaf(step, __uint_as_float(0x3d4cccceu), volts);
+      lanemask differ;
+      asm("v_cmp_neq_f32_e64 %0, %1, %2" : "=s"(differ) : "v"(r_lo), "v"(next3));
+      ok &= ~(differ & d.is3 & ~ge);
+      next = pick(d.is3 & ~ge, next3, next);
+#endif
     }
     asm("v_max_f32 %0, %1, %2" : "=v"(volts) : "v"(next), "v"(min_volts));  // :629 (no NaNs here)
     vo[k] = volts;
@@ -1203,7 +1247,11 @@ __device__ __forceinline__ void agc_chain_pipe(float *grp, float *stw0, size_t s
       AgcState t = st;
       AgcLane dt = d;
       lanemask ok;
+#ifdef T41RX_AGC_NO3  // timing experiment (wrong values): what is the double-precision decay step of state 3 worth?
+      if (false)
+#else
       if ((d.is3 & ~d.in0) != 0)
+#endif
         ok = agc_fast_block<true>(t, dt, gc, rm, pf, ph, vo);
       else
         ok = agc_fast_block<false>(t, dt, gc, rm, pf, ph, vo);
@@ -1410,13 +1458,25 @@ static_assert(!Geo<0>::kResident || (Geo<0>::kH1 + 24 <= Geo<0>::kSlice && Geo<0
 // Diagnostic build only (-DT41RX_CLK, tools/clock_probe.py): every wave leaves the shader-clock and the constant
 // 100 MHz counter's ticks between its start and its end here (its clock under this load = their ratio x 100 MHz).
 __device__ unsigned long long g_t41_clk[2 * 8192];
+#define T41RX_CLK_BEGIN()                                                                                              \
+  unsigned long long clk_c0, clk_r0;                                                                                   \
+  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk_c0), "=s"(clk_r0)::"memory")
+#define T41RX_CLK_END(wave_id)                                                                                         \
+  do {                                                                                                                 \
+    unsigned long long c1_, r1_;                                                                                       \
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c1_), "=s"(r1_)::"memory"); \
+    if ((threadIdx.x & 63) == 0 && (wave_id) < 8192) {                                                                 \
+      g_t41_clk[2 * (wave_id)] = c1_ - clk_c0;                                                                         \
+      g_t41_clk[2 * (wave_id) + 1] = r1_ - clk_r0;                                                                     \
+    }                                                                                                                  \
+  } while (0)
+#else
+#define T41RX_CLK_BEGIN() do {} while (0)
+#define T41RX_CLK_END(wave_id) do {} while (0)
 #endif
 template <int MODE, bool DEBUG, int PART, bool PLAIN, bool AGC = false, bool WQ15 = false, bool SEGPAR = false, bool PIPE = false>
 __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64), 4) void rx512_kernel(const RxArgs a) {
-#ifdef T41RX_CLK
-  unsigned long long clk_c0, clk_r0;
-  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk_c0), "=s"(clk_r0)::"memory");
-#endif
+  T41RX_CLK_BEGIN();
   static_assert(!SEGPAR || (PART == 1 && MODE != kModeNfm) || (PART == 2 && MODE == kModeSsb && !AGC), "SEGPAR variants");
   static_assert(!PIPE || ((AGC != (MODE == kModeSam)) && PART == 0 && !DEBUG && !SEGPAR && T41RX_RESIDENT),
                 "PIPE: the pipelined variants -- AGC on (see agc_prep_pipe), or the synchronous detector with the AGC off (sam_chain_pipe)");
@@ -1864,6 +1924,7 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
 
       STAMP(15);  // prologue d: NCO/DC state uniformisation + Q's DC-block start state
       cf y2[2][2];  // /8 outputs of this frame: m = 128*round + 2*lane + e
+      cf o1x[2] = {splat(0.0f), splat(0.0f)};  // (T41RX_LOO 13: the last /4 outputs, a register source for the /2 window)
       // (cos, sin) table entries of this lane's first sample of the four sub-blocks.  All four
       // are requested HERE and nowhere later: vector-memory results return in issue order, so a
       // table read issued between two input requests could only be used once every older input
@@ -2039,7 +2100,9 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
           // arm_fir_decimate_f32: y[m] = sum_i c[i] * state[4m + i]; state[i] = buf[i + 1]
           {
             auto pidx = [](int o) { return xpad(o); };  // window-relative, identical for every lane
-            if (!T41RX_CUT(4)) {
+            if (T41RX_LOO == 14) {
+              fir_pair<kDec1Taps, 1, 5, 18, 6>(xw, pidx, (CFloatPtr)cf0->dec1, o1[0], o1[1], z);
+            } else if (!T41RX_CUT(4)) {
               fir_pair<kDec1Taps, 1, 5, 18, 6>(xw, pidx, (CFloatPtr)cf0->dec1, o1[0], o1[1]);
             } else {
               o1[0] = *reinterpret_cast<cf *>(xw);
@@ -2056,6 +2119,7 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
             *reinterpret_cast<float4 *>(lds + kY1 + y1slot(24 + 64 * h + lane)) =
                 make_float4(o1[0].x, o1[0].y, o1[1].x, o1[1].y);
           }
+          if (T41RX_LOO == 13) { o1x[0] = o1[0]; o1x[1] = o1[1]; }
         }  // h
         STAMP(4);  // history roll
         if (rd == 1) { if (AGC) PRIO(1); else PRIO(2); }
@@ -2065,7 +2129,10 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
         {
           // window-relative complex offset o (even) -> offset in the planes, relative to lds + kY1 + 4 lane
           auto planes = [](int o) { return y1slot(o >> 1) / 2; };
-          if (!T41RX_CUT(3)) {
+          if (T41RX_LOO == 13) {
+            const cf src[8] = {y2[0][0], y2[0][1], o1x[0], o1x[1], y2[0][1], o1x[1], o1x[0], y2[0][0]};
+            fir_pair<kDec2Taps, 3, 5, 26, 6>(lds + kY1 + 4 * lane, planes, (CFloatPtr)cf0->dec2, y2[rd][0], y2[rd][1], src);
+          } else if (!T41RX_CUT(3)) {
             fir_pair<kDec2Taps, 3, 5, 26, 6>(lds + kY1 + 4 * lane, planes, (CFloatPtr)cf0->dec2, y2[rd][0], y2[rd][1]);
           } else {
             y2[rd][0] = *reinterpret_cast<cf *>(lds + kY1 + 4 * lane);
@@ -2881,16 +2948,7 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
       st[kStMisc + kMiscDc] = dc_carry;
     }
   }
-#ifdef T41RX_CLK
-  {
-    unsigned long long c1, r1;
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c1), "=s"(r1)::"memory");
-    if (lane == 0 && job < 8192) {
-      g_t41_clk[2 * job] = c1 - clk_c0;
-      g_t41_clk[2 * job + 1] = r1 - clk_r0;
-    }
-  }
-#endif
+  T41RX_CLK_END(job);
 }
 #ifdef T41RX_CLK
 extern "C" int t41rx_debug_read_clk(unsigned long long *host, int n) {
@@ -3326,6 +3384,7 @@ __global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_fuse
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ch = blockIdx.x;
   if (ch >= a.nchan) return;
+  T41RX_CLK_BEGIN();
   cf *A = reinterpret_cast<cf *>(smem);
   constexpr int kArr = fc_arr_floats(R);
   cf *ltw = reinterpret_cast<cf *>(smem + kArr);
@@ -3807,6 +3866,7 @@ __global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_fuse
     ncs_wr->phase = phase_call + (uint64_t)a.nframes * (uint64_t)L * dphi;
     ncs_wr->r = osc_r;
   }
+  T41RX_CLK_END(ch * NWV + wv);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -16,18 +16,22 @@ import torch  # noqa: E402
 import t41_sdr_amd as T  # noqa: E402
 from t41_sdr_amd import _lib  # noqa: E402
 
-L = 2048
-
-
 def opt(flag, default):
     a = sys.argv[1:]
     return type(default)(a[a.index(flag) + 1]) if flag in a else default
 
 
 def main():
-    nch, frames, reps = 4096, opt("--frames", 32), opt("--reps", 40)
+    fft = opt("--fft", 512)
+    nch, frames, reps = opt("--nch", 4096 if fft == 512 else 1024), opt("--frames", 32), opt("--reps", 40)
     layout = opt("--layout", "channel")
-    rx = T.RxChain(nch, T.default_params(mode=opt("--mode", 0), AGCMode=opt("--agc", 0)),
+    L = 4 * fft
+    kw = dict(mode=opt("--mode", 0), AGCMode=opt("--agc", 0), fft_length=fft)
+    if fft != 512:
+        kw.update(FLoCut=400, FHiCut=600)
+    if kw["mode"] in (2, 8):
+        kw.update(FLoCut=-3000, FHiCut=3000)
+    rx = T.RxChain(nch, T.default_params(**kw),
                    NCOFreq=(np.random.default_rng(1000).integers(-860, 801, nch) * 50).astype(np.int32))
     rx.set_buffer_layout(layout)
     shape = (nch, frames * L) if layout == "channel" else (frames, nch, L)
@@ -45,11 +49,12 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     lib = _lib.load()
-    buf = (C.c_ulonglong * (2 * nch))()
-    rc = lib.t41rx_debug_read_clk(buf, 2 * nch)
-    a = np.frombuffer(buf, dtype=np.uint64).astype(np.float64).reshape(nch, 2)
+    nw = nch if fft == 512 else 4 * nch  # waves that report (the fused long-FFT kernel runs four per channel)
+    buf = (C.c_ulonglong * (2 * nw))()
+    rc = lib.t41rx_debug_read_clk(buf, 2 * nw)
+    a = np.frombuffer(buf, dtype=np.uint64).astype(np.float64).reshape(nw, 2)
     ghz = a[:, 0] / a[:, 1] * 0.1
-    print(json.dumps({"rc": rc, "us_per_frame": round(e0.elapsed_time(e1) / reps * 1e3 / frames, 3),
+    print(json.dumps({"args": " ".join(sys.argv[1:]), "rc": rc, "us_per_frame": round(e0.elapsed_time(e1) / reps * 1e3 / frames, 3),
                       "clock_GHz_median": round(float(np.median(ghz)), 3), "min": round(float(ghz.min()), 3), "max": round(float(ghz.max()), 3),
                       "wave_life_us_median": round(float(np.median(a[:, 1])) / 100.0, 1),
                       "cycles_per_wave_frame": round(float(np.median(a[:, 0])) / frames)}), flush=True)

@@ -1973,31 +1973,34 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
               pQ0[h] = ldg_stream(gQ + o);
             }
           } else if (PART == 1 || (KEEP && kPF >= 1)) {  // the next segment's / frame's sub-blocks 0 and 1
-            // Requested UNCONDITIONALLY (the launch's last frame re-reads its own first sub-blocks, which nobody uses): a
-            // request under `if (f + 1 < seg1)` makes the register set a merge of old and new values -- 16 copies per
-            // sub-block -- and hipcc's wait for the sub-block in front of it a vmcnt(0), since it cannot count on a
-            // younger request having been issued (ISA of round 3's kernel).
+            // Requested UNCONDITIONALLY (behind the launch's last frame: from the constant table, 8 KiB of L2-resident
+            // values nobody uses -- no fabric traffic): a request under `if (f + 1 < seg1)` makes the register set a merge
+            // of old and new values -- 16 copies per sub-block -- and hipcc's wait for the sub-block in front of it a
+            // vmcnt(0), since it cannot count on a younger request having been issued (ISA of round 3's kernel).
             {
-              const size_t nstep = (f + 1 < seg1) ? fstep : 0;
+              static_assert(kTabEntries512 * 2 >= 2048 + 8, "the stand-in source of the last frame's prefetch covers a frame's offsets");
+              const bool more = f + 1 < seg1;
+              const float *nI = more ? gI + fstep : reinterpret_cast<const float *>(tab);
+              const float *nQ = more ? gQ + fstep : reinterpret_cast<const float *>(tab);
               if (KEEP && s == 3) {  // and the I tail that decides the next frame's Q start state
                 if (!WQ15) {
-                  tailN = *reinterpret_cast<const float4 *>(gI + nstep + (L - 256) + 4 * lane);
+                  tailN = *reinterpret_cast<const float4 *>(nI + (L - 256) + 4 * lane);
                 } else {  // (raw q15 words; converted when used, not here: that would wait for them)
-                  tailNq = *reinterpret_cast<const float2 *>(gI + nstep + (L - 256) / 2 + 2 * lane);
+                  tailNq = *reinterpret_cast<const float2 *>(nI + (L - 256) / 2 + 2 * lane);
                 }
               }
               if (KEEP && kPF < 2 && s == 3) {
                 // sub-block 1 is requested at the top of the next frame
               } else if (!WQ15) {
-                const size_t o = nstep + 512 * (s - 2) + 8 * lane;
-                pI0[h] = ldg_stream(gI + o);
-                pI1[h] = ldg_stream(gI + o + 4);
-                pQ0[h] = ldg_stream(gQ + o);
-                pQ1[h] = ldg_stream(gQ + o + 4);
+                const int o = 512 * (s - 2) + 8 * lane;
+                pI0[h] = ldg_stream(nI + o);
+                pI1[h] = ldg_stream(nI + o + 4);
+                pQ0[h] = ldg_stream(nQ + o);
+                pQ1[h] = ldg_stream(nQ + o + 4);
               } else {
-                const size_t o = nstep + 256 * (s - 2) + 4 * lane;
-                pI0[h] = ldg_stream(gI + o);
-                pQ0[h] = ldg_stream(gQ + o);
+                const int o = 256 * (s - 2) + 4 * lane;
+                pI0[h] = ldg_stream(nI + o);
+                pQ0[h] = ldg_stream(nQ + o);
               }
             }
           } else if (s == 3 && !KEEP) {  // last sub-block: prefetch the overlap-save "previous" block instead

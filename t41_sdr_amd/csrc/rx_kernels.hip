@@ -746,6 +746,98 @@ __device__ __forceinline__ lanemask agc_fast_block(AgcState &st, AgcLane &d, con
   return ok;
 }
 
+// Round 4: the same four steps with the shortest dependent path per step this arithmetic allows.  agc_fast_block()
+// above decides first (compare -> mask -> select the multiplier) and then computes, and takes state 3's decay step
+// through four double-precision instructions: ten dependent instructions and a VALU -> SGPR -> VALU hop per step, on
+// an in-order wave.  Here both candidates are computed from the difference at once -- attack: volts + diff * attack_mult,
+// stay: volts + diff * stay, the very products and sums the reference would have formed on either branch -- and selected
+// when the comparison, issued beside the subtraction, has long returned; state 3's decay value comes from two FMAs that
+// bracket the reference's double expression (c_lo < .05 < c_hi, second float neighbours: see T41RX_AGC_DECAY64 above for
+// why their agreement proves the value) instead of through double precision; and everything that only feeds masks
+// (the assumption check, save_volts, the state bookkeeping) waits for the end of the block, off the chain.  Dependent
+// path per step: subtract, multiply, add / FMA, two selects, max.  `sand` returns the lanes whose bracket did not close
+// in some step (their block is redone by agc_fast_block<true>, which has the double expression); the other result
+// is agc_fast_block()'s `ok`.
+template <bool HAS3>
+__device__ __forceinline__ lanemask agc_fast_block_s(AgcState &st, AgcLane &d, const AgcConsts &g, const float (&rm)[4],
+                                                     const float (&pf)[4], const float (&ph)[4], float (&vo)[4], lanemask &sand) {
+#pragma clang fp contract(off)
+  float volts = st.volts;
+  f2 back = f2{st.fast_backaverage, st.hang_backaverage};
+  const f2 onem = f2{g.onemfast_backmult, g.onemhang_backmult};
+  float attack_mult = g.attack_mult, min_volts = g.min_volts;
+  asm volatile("" : "+v"(attack_mult), "+v"(min_volts));  // v_cndmask / v_max operands: keep them in VGPRs
+  const float c_lo = __uint_as_float(0x3d4ccccbu), c_hi = __uint_as_float(0x3d4cccceu);
+  float vin[4];
+  lanemask ge[4], gt[4], df[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const f2 aged = onem * back;  // :525-526
+    back = f2{pf[k], ph[k]} + aged;
+    vin[k] = volts;
+    const float diff = rm[k] - volts;
+    ge[k] = lanes_ge(rm[k], volts);
+    gt[k] = lanes_gt(volts, d.thr);
+    const float sa = diff * attack_mult, ss = diff * d.stay;
+    const float na = volts + sa;
+    float cand = volts + ss;
+    df[k] = 0;
+    if (HAS3) {
+      const float r_lo = __builtin_fmaf(ss, c_lo, volts), r_hi = __builtin_fmaf(ss, c_hi, volts);
+      lanemask differ;
+      asm("v_cmp_neq_f32_e64 %0, %1, %2" : "=s"(differ) : "v"(r_lo), "v"(r_hi));
+      df[k] = differ;
+      cand = pick(d.is3, r_hi, cand);
+    }
+    const float next = pick(ge[k], na, cand);
+    asm("v_max_f32 %0, %1, %2" : "=v"(volts) : "v"(next), "v"(min_volts));  // :629 (no NaNs here)
+    vo[k] = volts;
+  }
+  // the block's bookkeeping, in step order
+  lanemask ok = ~(d.is2 & __builtin_amdgcn_ballot_w64(st.hang_counter <= 4));  // the hang counter cannot run out inside the block
+  lanemask in0 = d.in0, pend = d.pend, bad = 0;
+  float save_volts = st.save_volts;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    ok &= ge[k] | (gt[k] & ~in0);
+    if (HAS3) bad |= df[k] & d.is3 & ~ge[k];
+    save_volts = pick(ge[k] & pend, vin[k], save_volts);  // the first attack out of 2, 3, 4
+    pend &= ~ge[k];
+    in0 |= ge[k];
+  }
+  sand = bad;
+  st.fast_backaverage = back.x;
+  st.hang_backaverage = back.y;
+  st.volts = volts;
+  st.save_volts = save_volts;
+  st.state = __float_as_int(pick(in0, __int_as_float(0), __int_as_float(st.state)));
+  const int hc = st.hang_counter - 4;
+  st.hang_counter = hc > 0 ? hc : 0;
+  d.pend = pend;
+  d.in0 = in0;
+  return ok;
+}
+#ifndef T41RX_AGC_SPEC
+#define T41RX_AGC_SPEC 1  // 0: round 3's fast block only (A/B, tools/agc_decay_check.py)
+#endif
+// one block of four steps by the fastest form that is exact for it
+__device__ __forceinline__ lanemask agc_block(AgcState &t, AgcLane &dt, const AgcState &st, const AgcLane &d, const AgcConsts &g,
+                                              const float (&rm)[4], const float (&pf)[4], const float (&ph)[4], float (&vo)[4]) {
+  const bool has3 = (d.is3 & ~d.in0) != 0;
+#if T41RX_AGC_SPEC
+  lanemask sand = 0;
+  lanemask ok = has3 ? agc_fast_block_s<true>(t, dt, g, rm, pf, ph, vo, sand) : agc_fast_block_s<false>(t, dt, g, rm, pf, ph, vo, sand);
+  if (sand != 0) {  // a rounding boundary between the bracketing values somewhere: the double expression decides
+    t = st;
+    dt = d;
+    ok = agc_fast_block<true>(t, dt, g, rm, pf, ph, vo);
+  }
+  return ok;
+#else
+  return has3 ? agc_fast_block<true>(t, dt, g, rm, pf, ph, vo) : agc_fast_block<false>(t, dt, g, rm, pf, ph, vo);
+#endif
+}
+
 // ---- AMDecodeSAM's loop (Demod.cpp:69-117) for one channel per lane: zs = the channel's 256 complex samples
 // (audio replaces the real parts), T = arm_sin_f32's table in LDS, ms = the channel's kStMisc words.
 // As written there: the fade leveler's time constants are exp(-1 / 24000 * tau) = exp(0) = 1 (integer
@@ -889,11 +981,7 @@ __device__ __forceinline__ void agc_chain(float *sl, CoefPtr cf0, int lane STAMP
     float vo[4];
     AgcState t = st;
     AgcLane dt = d;
-    lanemask ok;
-    if ((d.is3 & ~d.in0) != 0)
-      ok = agc_fast_block<true>(t, dt, g, rm, pf, ph, vo);
-    else
-      ok = agc_fast_block<false>(t, dt, g, rm, pf, ph, vo);
+    const lanemask ok = agc_block(t, dt, st, d, g, rm, pf, ph, vo);
     if (~ok != 0) {  // some lane changes state other than by an attack
       STAMP(24);  // chain: fast blocks
       // only those lanes redo the block (the others' results stand): the lanes that share a
@@ -1232,29 +1320,21 @@ __device__ __forceinline__ void agc_chain_pipe(float *grp, float *stw0, size_t s
 #ifdef T41RX_PIPE_STAT
     const unsigned long long ts1 = __builtin_readcyclecounter();
 #endif
-    float4 nr4 = lds4(sw), npa = lds4(sw + 16), npb = lds4(sw + 20);
+    // The next block's operands are requested at the top of a block and taken over at its END, behind the four steps:
+    // by then they have long landed.  (Round 3 took them over at the top of the next block, i.e. waited out an LDS round
+    // trip per block behind fifteen other waves' traffic; the request is unconditional -- the last block re-reads its
+    // own -- so the registers are not a merge of old and new values.)
+    float4 r4 = lds4(sw), pa4 = lds4(sw + 16), pb4 = lds4(sw + 20);
 #pragma nounroll
     for (int b = 0; b < 4; ++b) {
-      const float4 r4 = nr4, pa4 = npa, pb4 = npb;
-      if (b < 3) {
-        nr4 = lds4(sw + 4 * b + 4);
-        npa = lds4(sw + 16 + 8 * b + 8);
-        npb = lds4(sw + 16 + 8 * b + 12);
-      }
+      const int bn = b < 3 ? b + 1 : 3;
+      float4 nr4 = lds4(sw + 4 * bn), npa = lds4(sw + 16 + 8 * bn), npb = lds4(sw + 16 + 8 * bn + 4);
       const float rm[4] = {r4.x, r4.y, r4.z, r4.w};
       const float pf[4] = {pa4.x, pa4.z, pb4.x, pb4.z}, ph[4] = {pa4.y, pa4.w, pb4.y, pb4.w};
       float vo[4];
       AgcState t = st;
       AgcLane dt = d;
-      lanemask ok;
-#ifdef T41RX_AGC_NO3  // timing experiment (wrong values): what is the double-precision decay step of state 3 worth?
-      if (false)
-#else
-      if ((d.is3 & ~d.in0) != 0)
-#endif
-        ok = agc_fast_block<true>(t, dt, gc, rm, pf, ph, vo);
-      else
-        ok = agc_fast_block<false>(t, dt, gc, rm, pf, ph, vo);
+      const lanemask ok = agc_block(t, dt, st, d, gc, rm, pf, ph, vo);
       if (~ok != 0) {
 #ifdef T41RX_PIPE_STAT
         acc_slow += 1;
@@ -1268,6 +1348,10 @@ __device__ __forceinline__ void agc_chain_pipe(float *grp, float *stw0, size_t s
       st = t;
       d = dt;
       *reinterpret_cast<float4 *>(sw + 4 * b) = make_float4(vo[0], vo[1], vo[2], vo[3]);  // (every lane of a channel writes the same)
+      asm volatile("" : "+v"(vo[3]));  // (the take-over below stays behind the steps)
+      r4 = nr4;
+      pa4 = npa;
+      pb4 = npb;
     }
     wave_sync();
 #ifdef T41RX_PIPE_STAT

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""Round 4: state 3's decay step as one FMA + an exactness check (rx_kernels.hip, agc_fast_block) against the
-reference's double-precision expression in every block (-DT41RX_AGC_DECAY64=1): outputs and checkpoints must be
-identical bit for bit over long streams of every AGC mode, envelope and kernel form.
+"""Round 4: the AGC chain's speculative fast block (rx_kernels.hip, agc_fast_block_s: both candidates computed, state 3's
+decay step bracketed by two FMAs) against round 3's fast block, which decides first and takes the decay step through
+double precision (-DT41RX_AGC_SPEC=0): outputs and checkpoints must be identical bit for bit over long streams of every
+AGC mode, envelope and kernel form.
 
-  tools/build_variant.sh decay64 -DT41RX_AGC_DECAY64=1
+  tools/build_variant.sh spec0 -DT41RX_AGC_SPEC=0
   python tools/agc_decay_check.py [--streams 24] [--frames 96]         (GPU box: runs itself once per library)
 """
 import hashlib
@@ -14,6 +15,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 L = 2048
+REF = "spec0"  # the build to compare the product with (tools/build_variant.sh spec0 -DT41RX_AGC_SPEC=0: round 3's fast block only)
 
 
 def opt(flag, default):
@@ -62,7 +64,7 @@ def main():
     if "--worker" in sys.argv:
         return worker()
     res = {}
-    for name in ("product", "decay64"):
+    for name in ("product", REF):
         env = dict(os.environ)
         env.pop("T41RX_LIB", None)
         if name != "product":
@@ -72,7 +74,7 @@ def main():
         if p.returncode != 0 or not lines:
             raise SystemExit("%s failed: %s" % (name, p.stderr[-500:]))
         res[name] = json.loads(lines[0])
-    same = [a == b for a, b in zip(res["product"], res["decay64"])]
+    same = [a == b for a, b in zip(res["product"], res[REF])]
     print(json.dumps({"streams": len(same), "identical": sum(same), "mismatching_streams": [i for i, s in enumerate(same) if not s]}))
     if not all(same):
         raise SystemExit(1)

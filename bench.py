@@ -59,6 +59,9 @@ WORKLOADS = {
     "sam": dict(batch=4096, fft=512, kw=dict(mode=8, FLoCut=-3000, FHiCut=3000),
                 name="synchronous AM (AMDecodeSAM, Demod.cpp:40-139: a per-sample PLL, serial in time; SURVEY 8f rank 4), "
                      "4096 channels x 2048 samples per frame"),
+    "sam_agc": dict(batch=4096, fft=512, kw=dict(mode=8, FLoCut=-3000, FHiCut=3000, AGCMode=1),
+                    name="synchronous AM behind the firmware's default AGCMode = 1 (Demod.cpp:40-139 behind DSP_Fn.cpp:504-631): two serial "
+                         "chains per frame, each on a duty wave of its own (round 4), 4096 channels x 2048 samples per frame"),
     "ssb_agc": dict(batch=4096, fft=512, kw=dict(mode=0, FLoCut=200, FHiCut=3000, AGCMode=1),
                     name="configs[1] with the firmware's default AGCMode = 1 (look-ahead AGC, DSP_Fn.cpp:504-631) instead of "
                          "the fixed gain: 4096 channels x 2048 samples per frame (SURVEY 8f rank 1)"),

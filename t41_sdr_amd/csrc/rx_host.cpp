@@ -621,9 +621,10 @@ int process_device_impl(t41rx_ctx *ctx, const float *dI, const float *dQ, float 
   }
   a.agc = ctx->params.AGCMode != 0 ? 1 : 0;
   // the pipelined kernels' slots: AGC on (every mode but SAM), or the synchronous detector with the AGC off
-  if ((a.agc != 0) != (ctx->params.mode == T41RX_DEMOD_SAM) && seg == 1 && n_frames >= 4) {
-    if (!ctx->d_agc_pipe) {  // (+ 8 counters per wave of the -DT41RX_PIPE_STAT diagnostic build)
-      const size_t bytes = (size_t)ctx->nchan * 3 * 1024 * sizeof(float) + ((size_t)ctx->nchan + 16) * 16 * sizeof(unsigned long long);
+  if ((a.agc != 0 || ctx->params.mode == T41RX_DEMOD_SAM) && seg == 1 && n_frames >= 4) {
+    if (!ctx->d_agc_pipe) {  // (+ 8 counters per wave of the -DT41RX_PIPE_STAT diagnostic build; behind them the second
+      // stage's slots: the synchronous detector behind the AGC runs two chains per frame, rx_kernels.hip PSA)
+      const size_t bytes = 2 * (size_t)ctx->nchan * 3 * 1024 * sizeof(float) + ((size_t)ctx->nchan + 16) * 16 * sizeof(unsigned long long);
       float *slots = nullptr;  // the context only ever sees a buffer whose counters are zero
       HIP_TRY(hipMalloc((void **)&slots, bytes));
       const hipError_t em = hipMemset(slots, 0, bytes);

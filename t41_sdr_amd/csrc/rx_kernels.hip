@@ -1562,9 +1562,13 @@ template <int MODE, bool DEBUG, int PART, bool PLAIN, bool AGC = false, bool WQ1
 __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64), 4) void rx512_kernel(const RxArgs a) {
   T41RX_CLK_BEGIN();
   static_assert(!SEGPAR || (PART == 1 && MODE != kModeNfm) || (PART == 2 && MODE == kModeSsb && !AGC), "SEGPAR variants");
-  static_assert(!PIPE || ((AGC != (MODE == kModeSam)) && PART == 0 && !DEBUG && !SEGPAR && T41RX_RESIDENT),
-                "PIPE: the pipelined variants -- AGC on (see agc_prep_pipe), or the synchronous detector with the AGC off (sam_chain_pipe)");
-  constexpr bool PSAM = PIPE && MODE == kModeSam;
+  static_assert(!PIPE || ((AGC || MODE == kModeSam) && PART == 0 && !DEBUG && !SEGPAR && T41RX_RESIDENT),
+                "PIPE: the pipelined variants -- AGC on (see agc_prep_pipe), the synchronous detector with the AGC off (sam_chain_pipe), or both (PSA)");
+  constexpr bool PSAM = PIPE && MODE == kModeSam && !AGC;
+  // round 4: the synchronous detector behind the AGC -- TWO serial chains per frame, each on a duty wave of its own,
+  // four frames deep: front end + AGC preparation (f), AGC chain (f - 1), gain + hand-over to the PLL (f - 2), PLL
+  // chain (f - 3), interpolators and stores (f - 4).  Two instances of the same three-slot protocol in a row.
+  constexpr bool PSA = PIPE && MODE == kModeSam && AGC;
   // input sub-blocks of the NEXT frame requested across the back end (the pipelined kernels hold them across the
   // preparation, a chain and the back end of an older frame: registers that spill there)
   constexpr int kPF = PSAM ? T41RX_PIPE_PF_SAM : PIPE ? T41RX_PIPE_PF : T41RX_PF;
@@ -1606,8 +1610,8 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
       else if (threadIdx.x >= 256 && threadIdx.x < 256 + 56)
         reinterpret_cast<float2 *>(smem)[G::kTw2 + threadIdx.x - 256] =
             a.tab[kTabTw2 + 64 * ((threadIdx.x - 256) >> 3) + ((threadIdx.x - 256) & 7)];
-      else if (PIPE && threadIdx.x >= 320 && threadIdx.x < 328)
-        reinterpret_cast<unsigned *>(smem)[kPipeFlags + threadIdx.x - 320] = 0u;  // ready[3], done (see agc_prep_pipe)
+      else if (PIPE && threadIdx.x >= 320 && threadIdx.x < 332)
+        reinterpret_cast<unsigned *>(smem)[kPipeFlags + threadIdx.x - 320] = 0u;  // ready[3], done, claim (see agc_prep_pipe); PSA: the PLL stage's five behind them
     } else if (MODE == kModeSam) {
       // the mask is read from the L2-resident table (as the resident kernels do); its place holds
       // arm_sin_f32's 513-entry table for the PLL's per-lane look-ups
@@ -1719,7 +1723,7 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
     }
   };
   // PIPE: the back end trails the front end by two frames (see agc_prep_pipe): two more iterations
-  constexpr int kSkew = PIPE ? 2 : 0;
+  constexpr int kSkew = PSA ? 4 : PIPE ? 2 : 0;
   for (int f = seg0; f < seg1 + kSkew; ++f) {
 #ifdef T41RX_PIPE_STAT
     unsigned long long ps_t = __builtin_readcyclecounter();  // [8] front end [9] AGC preparation [10] back end [11] iterations
@@ -1739,7 +1743,7 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
     const float *__restrict__ gQ = a.Q + (WQ15 ? fbase / 2 : fbase);
     float *__restrict__ gO = a.out + (WQ15 ? fbase_o / 2 : fbase_o);
 
-    constexpr bool CONTIG = (MODE == kModeAm) || (AGC && MODE != kModeSam) || PSAM;  // aud[j] = sample 4 lane + j instead of lane + 64 j
+    constexpr bool CONTIG = (MODE == kModeAm) || (AGC && MODE != kModeSam) || PSAM || PSA;  // aud[j] = sample 4 lane + j instead of lane + 64 j
     float aud[4];                            // 4 demodulated samples @24 kS/s
     float4 agst = make_float4(0, 0, 0, 0);   // AGC record (delay line + state words), one float4 per lane
     float4 hist1 = make_float4(0, 0, 0, 0);  // x2 interpolator history (lanes 0..5)
@@ -2190,6 +2194,8 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
             if (T41RX_LOO == 14) {
               fir_pair<kDec1Taps, 1, 5, 18, 6>(xw, pidx, (CFloatPtr)cf0->dec1, o1[0], o1[1], z);
             } else if (!T41RX_CUT(4)) {
+              // (round 4, measured and dropped: the window requested one group ahead of its use behind scheduling
+              //  barriers, taps in 16-tap scalar loads -- 18 spilled registers, 26.7 against 22.4 us per frame)
               fir_pair<kDec1Taps, 1, 5, 18, 6>(xw, pidx, (CFloatPtr)cf0->dec1, o1[0], o1[1]);
             } else {
               o1[0] = *reinterpret_cast<cf *>(xw);
@@ -2528,7 +2534,87 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
       // SSB/NFM: audio = Re
       const float fixed_gain = fresh_coef(cf0)->sc[kScFixedGain];
       cf og[4];
-      if (PIPE) {
+      if (PSA) {
+        const int left = a.nchan - NW * (int)blockIdx.x;
+        const int nvalid = left < NW ? left : NW;
+        unsigned *fa = reinterpret_cast<unsigned *>(smem) + kPipeFlags;  // AGC stage: ready[3], done, claim
+        unsigned *fs = fa + 5;                                           // PLL stage: the same five words
+        unsigned *pipe_err = reinterpret_cast<unsigned *>(reinterpret_cast<unsigned long long *>(a.agc_pipe + (size_t)a.nchan * kPipeSlots * kPipeSlotFloats) +
+                                                          ((size_t)a.nchan + 15) * 16);
+        // the PLL stage's slots lie behind the AGC stage's and the diagnostic words (rx_host.cpp allocates both)
+        float *sam_slots = a.agc_pipe + (size_t)a.nchan * kPipeSlots * kPipeSlotFloats + ((size_t)a.nchan + 16) * 32;
+        const size_t ch0 = (size_t)NW * blockIdx.x;
+        auto claim = [&](unsigned *word, int g) -> bool {  // the first wave to get here takes frame g's chain
+          unsigned won = 0u;
+          if (lane == 0) {
+            unsigned expect = (unsigned)g;
+            won = __hip_atomic_compare_exchange_strong(word, &expect, (unsigned)(g + 1), __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1u : 0u;
+          }
+          return __builtin_amdgcn_readfirstlane(won) != 0u;
+        };
+        static_assert(!PSA || (NW == 16 && kScr + kPipeStageFloats <= G::kXF && kScr + kPipeSamStageFloats <= G::kXF), "chain staging inside the X scratch");
+        // ---- stage A: this frame's AGC operands and popped samples -> the channel's slot
+        if (f < seg1) {
+          float *pslot = a.agc_pipe + ((size_t)ch * kPipeSlots + f % kPipeSlots) * kPipeSlotFloats;
+          if (first_iter) agmag = make_float2(agc_mag(cf{agrec.x, agrec.y}), agc_mag(cf{agrec.z, agrec.w}));  // (later frames: carried)
+          agrec = agc_prep_pipe<AgcLds<true>, true>(v, agrec, agmag, lds, pslot, cf0, lane);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          if (lane == 0) __hip_atomic_fetch_add(fa + f % kPipeSlots, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        // ---- duty 1: the AGC chain of frame f - 1
+        {
+          const int g = f - 1;
+          if (g >= seg0 && g < seg1 && claim(fa + 4, g)) {
+            pipe_wait_ge(fa + g % kPipeSlots, (unsigned)nvalid, pipe_err);
+            if (lane == 0) __hip_atomic_store(fa + g % kPipeSlots, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            PRIO(3);
+            unsigned long long *pipe_stat = reinterpret_cast<unsigned long long *>(a.agc_pipe + (size_t)a.nchan * kPipeSlots * kPipeSlotFloats) + (size_t)job * 16;
+            agc_chain_pipe(a.agc_pipe + (ch0 * kPipeSlots + g % kPipeSlots) * kPipeSlotFloats, a.state + ch0 * state_stride + st_agc(512) + kAgcHistFloats,
+                           state_stride, lds + kScr, fa + 3, (unsigned)g, nvalid, cf0, lane, pipe_stat, pipe_err);
+            PRIO(1);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) __hip_atomic_store(fa + 3, (unsigned)(g + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+        // ---- stage B: gain of frame f - 2 (its chain is done), the scaled samples -> the PLL stage's slot, time order
+        {
+          const int fm = f - 2;
+          if (fm >= seg0 && fm < seg1) {
+            pipe_wait_ge(fa + 3, (unsigned)(fm + 1), pipe_err);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const AgcGainIn gin = agc_gain_request<true>(a.agc_pipe + ((size_t)ch * kPipeSlots + fm % kPipeSlots) * kPipeSlotFloats, lane);
+            agc_gain_pipe(gin, cf0, og);
+            float *sslot = sam_slots + ((size_t)ch * kPipeSlots + fm % kPipeSlots) * kPipeSlotFloats;
+            *reinterpret_cast<float4 *>(sslot + 8 * lane) = make_float4(og[0].x, og[0].y, og[1].x, og[1].y);  // samples 4 lane, 4 lane + 1
+            *reinterpret_cast<float4 *>(sslot + 8 * lane + 4) = make_float4(og[2].x, og[2].y, og[3].x, og[3].y);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) __hip_atomic_fetch_add(fs + fm % kPipeSlots, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+        // ---- duty 2: the PLL of frame f - 3
+        {
+          const int g = f - 3;
+          if (g >= seg0 && g < seg1 && claim(fs + 4, g)) {
+            pipe_wait_ge(fs + g % kPipeSlots, (unsigned)nvalid, pipe_err);
+            if (lane == 0) __hip_atomic_store(fs + g % kPipeSlots, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            PRIO(3);
+            sam_chain_pipe(sam_slots + (ch0 * kPipeSlots + g % kPipeSlots) * kPipeSlotFloats, a.state + ch0 * state_stride + kStMisc, state_stride,
+                           lds + kScr, reinterpret_cast<const float *>(a.tab + kTabSam), fs + 3, (unsigned)g, nvalid, cf0, lane, pipe_err);
+            PRIO(1);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) __hip_atomic_store(fs + 3, (unsigned)(g + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+        if (f < seg0 + kSkew) continue;  // nothing to finish yet
+        // ---- stage C: the audio of frame f - 4
+        pipe_wait_ge(fs + 3, (unsigned)(fb + 1), pipe_err);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        {
+          const float4 au = *reinterpret_cast<const float4 *>(sam_slots + ((size_t)ch * kPipeSlots + fb % kPipeSlots) * kPipeSlotFloats + 512 + 4 * lane);
+          aud[0] = au.x, aud[1] = au.y, aud[2] = au.z, aud[3] = au.w;
+        }
+        if (KEEP) hist2 = hist2c;
+      } else if (PIPE) {
         const int left = a.nchan - NW * (int)blockIdx.x;
         const int nvalid = left < NW ? left : NW;
         unsigned *flags = reinterpret_cast<unsigned *>(smem) + kPipeFlags;
@@ -2631,7 +2717,7 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
         agc_apply<AgcLds<KEEP>, NW, G::kSlice>(v, agst, lds, smem + G::kTab, st + st_agc(512 * seg), cf0, lane, wv,
                                                left < NW ? left : NW, og STAMP_ARGS);
       }
-      if (PSAM) {
+      if (PSAM || PSA) {
         // (the audio came out of the slot above)
       } else if (MODE == kModeSam) {
         // ---- synchronous AM, AMDecodeSAM() Demod.cpp:40-139: a PLL, one sample at a time.  Every wave
@@ -4306,6 +4392,12 @@ hipError_t launch_rx(const RxArgs &a, int fft_length, int mode, hipStream_t s) {
         const dim3 g16((a.nchan + Geo<0>::kWaves - 1) / Geo<0>::kWaves), b16(Geo<0>::kWaves * 64);
         if (a.q15) hipLaunchKernelGGL((rx512_kernel<kModeSam, false, 0, false, false, true, false, true>), g16, b16, 0, s, a);
         else hipLaunchKernelGGL((rx512_kernel<kModeSam, false, 0, false, false, false, false, true>), g16, b16, 0, s, a);
+        return hipGetLastError();
+      }
+      if (a.agc && a.agc_pipe && !debug && a.nframes >= 4 && pipe_env) {  // round 4: AGC chain and PLL, each on a duty wave of its own (PSA)
+        const dim3 g16((a.nchan + Geo<0>::kWaves - 1) / Geo<0>::kWaves), b16(Geo<0>::kWaves * 64);
+        if (a.q15) hipLaunchKernelGGL((rx512_kernel<kModeSam, false, 0, false, true, true, false, true>), g16, b16, 0, s, a);
+        else hipLaunchKernelGGL((rx512_kernel<kModeSam, false, 0, false, true, false, false, true>), g16, b16, 0, s, a);
         return hipGetLastError();
       }
       const int grid = (a.nchan + 3) / 4;

@@ -312,3 +312,32 @@ def test_gpu_switch_to_sam_mid_stream(built):
     rb = ob.process(np.ascontiguousarray(I[:, n0 * L:]), np.ascontiguousarray(Q[:, n0 * L:]))
     assert siggen.block_rel_err(a, ra, L).max() <= 1e-5
     assert siggen.block_rel_err(b, rb, L)[:, LOCKED:].max() <= 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("agc", [1, 2, 3, 4], ids=["agc-long", "agc-slow", "agc-med", "agc-fast"])
+def test_gpu_sam_with_agc_pipelined_equals_barrier_form(built, agc):
+    """Round 4: the synchronous detector behind the AGC (the firmware's default AGCMode = 1,
+    gwv.cpp:15; Demod.cpp:40-139 behind DSP_Fn.cpp:504-631) on the pipelined kernel -- AGC chain and PLL each on a duty
+    wave of their own, five frames in flight -- for calls of four frames or more; shorter calls run the barrier form.
+    Same samples, same PLL / AGC state, bit for bit, in every AGC mode, on full and ragged workgroups and across
+    mixed call lengths; against the oracle once locked."""
+    import t41_sdr_amd as T
+    kw = dict(KW, AGCMode=agc)
+    for nch, nfr in ((16, 14), (21, 12), (1, 9), (37, 10)):
+        nco = siggen.nco_grid(nch, seed=60 + nch)
+        I, Q = siggen.make_am_carrier(nch, nfr * L, nco, seed=300 + 10 * agc + nch)
+        I, Q = siggen.fade(I, Q, [(0.3, 1.5), (0.3, 0.08), (0.4, 1.2)])  # so that the gain law walks through its states
+        whole, rx_w = _gpu_run(T, kw, nco, I, Q, [nfr])                                  # one call: pipelined
+        short, rx_s = _gpu_run(T, kw, nco, I, Q, [3] * (nfr // 3) + ([nfr % 3] if nfr % 3 else []))  # barrier form only
+        mixed, rx_m = _gpu_run(T, kw, nco, I, Q, [4, 1, nfr - 5])                      # pipelined, barrier, pipelined
+        assert np.isfinite(whole).all()
+        assert np.array_equal(whole, short) and np.array_equal(whole, mixed), (agc, nch)
+        assert np.array_equal(rx_w.get_state(), rx_s.get_state()) and np.array_equal(rx_w.get_state(), rx_m.get_state()), (agc, nch)
+    nch, nfr = 24, 20
+    nco = siggen.nco_grid(nch, seed=61)
+    I, Q = siggen.make_am_carrier(nch, nfr * L, nco, seed=340 + agc)
+    got, _ = _gpu_run(T, kw, nco, I, Q, [nfr])
+    ref = O.OracleBatch(O.default_params(**kw), np.asarray(nco, np.int32)).process(I, Q, nthreads=8)
+    err = siggen.block_rel_err(got, ref, L)
+    assert err[:, LOCKED:].max() <= 1e-5, err[:, LOCKED:].max()

@@ -27,7 +27,7 @@ def main():
         nch = 4096 if big else int(rng.choice([1, 2, 3, 5, 15, 16, 17, 31, 33, 64, 100, 255, 256, 300, 1000]))
         nfr = 32 if big else int(rng.integers(4, 41))
         mode = int(rng.choice([0, 1, 2, 3, 8]))
-        agc = 0 if mode == 8 else int(rng.integers(1, 5))
+        agc = int(rng.integers(0, 5)) if mode == 8 else int(rng.integers(1, 5))  # (SAM: PLL alone, or behind the AGC -- two chains)
         flo, fhi = {0: (200, 3000), 1: (-3000, -200), 2: (-3000, 3000), 3: (200, 3000), 8: (-3000, 3000)}[mode]
         kw = dict(mode=mode, AGCMode=agc, FLoCut=flo, FHiCut=fhi)
         nco = (rng.integers(-860, 801, nch) * 50).astype(np.int32)

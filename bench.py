@@ -324,7 +324,7 @@ def dry_run(args, world, rank):
         raise SystemExit("rank %d: broadcast coefficient blob differs from rank 0's design" % rank)
     wall = 1.0 + rank
     # the device every rank would select (torch.cuda.set_device(LOCAL_RANK) in the real run): one GPU each
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = int(os.environ.get("T41RX_BENCH_FORCE_LOCAL_RANK", os.environ.get("LOCAL_RANK", "0")))  # (test hook: a broken launcher)
     local_ranks = [local_rank]
     if world > 1:
         wall = max_over_ranks(wall)

@@ -107,3 +107,11 @@ def test_bench_refuses_a_world_size_mismatch(built):
 def test_bench_launcher_propagates_a_failing_rank(built):
     p, lines = _run_bench(["--gpus", "2", "--dry-run", "--workload", "ssb"], env_extra=dict(T41RX_BENCH_FAIL_RANK="1"))
     assert p.returncode != 0 and not lines
+
+
+def test_bench_refuses_two_ranks_on_one_device(built):
+    """a launcher that hands both ranks the same device would read as perfect scaling: every rank's device is gathered
+    and a duplicate ends the run (the real run gathers the devices' uuids the same way, bench.py main())"""
+    p, lines = _run_bench(["--gpus", "2", "--dry-run", "--workload", "ssb"], env_extra=dict(T41RX_BENCH_FORCE_LOCAL_RANK="0"))
+    assert p.returncode != 0 and not lines
+    assert "same device" in (p.stderr + p.stdout)

@@ -838,6 +838,82 @@ __device__ __forceinline__ lanemask agc_block(AgcState &t, AgcLane &dt, const Ag
 #endif
 }
 
+// Round 4, second step: agc_fast_block_s() in three phases for agc_chain_pipe(), whose wave issues one instruction per
+// ~4-5 cycles whatever it is -- what paces the chain is the COUNT of instructions per block (150 in the form above: 122 in
+// the block, the rest moves), so this form exists to have fewer:
+//   * the two candidates of a step as packed pairs: (diff, diff) x (attack_mult, stay) is one v_pk_mul_f32, volts + both
+//     products one v_pk_add_f32, the bracketing pair of state 3 one v_pk_fma_f32 with (c_lo, c_hi) -- the same products,
+//     sums and FMAs on the same values, three instructions instead of six per step;
+//   * the steps need the four ring maxima only, so the back-averages' operands are requested at the top of the block they
+//     belong to and used two steps later, and only the NEXT block's ring maxima ride in prefetch registers: 4 moves per
+//     block instead of 12.  (Reading them at the block's end into the registers the steps have just finished with -- no
+//     move at all -- exposes an LDS round trip per block behind fifteen other waves' traffic: measured, no gain);
+//   * the bracket's verdict is taken per block: (df0 | df1 | df2 | df3) & is3 instead of a mask expression per step (a
+//     lane that attacked at the one step in ten thousand where its bracket stayed open takes the double-precision
+//     block although it would not have had to: same values).
+// Every float operation is one of agc_fast_block_s()'s on the same operands: bit-identical (T41RX_AGC_PHASED=0 builds the
+// form above; tools/agc_decay_check.py, the pipelined == barrier tests and tools/pipe_soak.py compare them).
+#ifndef T41RX_AGC_PHASED
+#define T41RX_AGC_PHASED 1
+#endif
+// (the bookkeeping of a step and the back-averages are written between the steps: they fill the issue slots the dependent
+// chain sub -> mul -> add / fma -> select -> select -> max leaves open; measured with all of it behind the four steps: 1.5 %
+// slower than the unpacked form, the steps then run one instruction per dependency stall)
+template <bool HAS3>
+__device__ __forceinline__ lanemask agc_block_phased(AgcState &st, AgcLane &d, const AgcConsts &g, f2 mult /* (attack_mult, stay) */,
+                                                     float min_volts, const float4 r4, const float4 pa4, const float4 pb4,
+                                                     float (&vo)[4], lanemask &sand) {
+#pragma clang fp contract(off)
+  const float rm[4] = {r4.x, r4.y, r4.z, r4.w};
+  const f2 pp[4] = {f2{pa4.x, pa4.y}, f2{pa4.z, pa4.w}, f2{pb4.x, pb4.y}, f2{pb4.z, pb4.w}};
+  const f2 cb = f2{__uint_as_float(0x3d4ccccbu), __uint_as_float(0x3d4cccceu)};  // second float neighbours of .05 (see above)
+  const f2 onem = f2{g.onemfast_backmult, g.onemhang_backmult};
+  float volts = st.volts, save_volts = st.save_volts;
+  f2 back = f2{st.fast_backaverage, st.hang_backaverage};
+  lanemask ok = ~(d.is2 & __builtin_amdgcn_ballot_w64(st.hang_counter <= 4));  // the hang counter cannot run out inside the block
+  lanemask in0 = d.in0, pend = d.pend, df = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float vin = volts;
+    const float diff = rm[k] - volts;
+    const lanemask ge = lanes_ge(rm[k], volts);
+    const lanemask gt = lanes_gt(volts, d.thr);
+    const f2 s2 = splat(diff) * mult;   // (diff * attack_mult, diff * stay)
+    const f2 n2 = splat(volts) + s2;    // (attack candidate, stay candidate)
+    float cand = n2.y;
+    if (HAS3) {
+      const f2 r = pk_fma(splat(s2.y), cb, splat(volts));
+      lanemask differ;
+      asm("v_cmp_neq_f32_e64 %0, %1, %2" : "=s"(differ) : "v"(r.x), "v"(r.y));
+      df |= differ;
+      cand = pick(d.is3, r.y, cand);
+    }
+    const float next = pick(ge, n2.x, cand);
+    asm("v_max_f32 %0, %1, %2" : "=v"(volts) : "v"(next), "v"(min_volts));  // :629 (no NaNs here)
+    vo[k] = volts;
+    // the step's bookkeeping and (two steps behind: their operands were requested at the top of the block) the back-averages
+    ok &= ge | (gt & ~in0);
+    save_volts = pick(ge & pend, vin, save_volts);  // the first attack out of 2, 3, 4
+    pend &= ~ge;
+    in0 |= ge;
+    if (k >= 2) {
+      back = pp[2 * (k - 2)] + onem * back;  // :525-526
+      back = pp[2 * (k - 2) + 1] + onem * back;
+    }
+  }
+  sand = HAS3 ? (df & d.is3) : 0;
+  st.fast_backaverage = back.x;
+  st.hang_backaverage = back.y;
+  st.volts = volts;
+  st.save_volts = save_volts;
+  st.state = __float_as_int(pick(in0, __int_as_float(0), __int_as_float(st.state)));
+  const int hc = st.hang_counter - 4;
+  st.hang_counter = hc > 0 ? hc : 0;
+  d.pend = pend;
+  d.in0 = in0;
+  return ok;
+}
+
 // ---- AMDecodeSAM's loop (Demod.cpp:69-117) for one channel per lane: zs = the channel's 256 complex samples
 // (audio replaces the real parts), T = arm_sin_f32's table in LDS, ms = the channel's kStMisc words.
 // As written there: the fade leveler's time constants are exp(-1 / 24000 * tau) = exp(0) = 1 (integer
@@ -1256,6 +1332,10 @@ __device__ __forceinline__ void agc_chain_pipe(float *grp, float *stw0, size_t s
   gc.hang_count = (int)c->agc[kAgcHangCount];
   float fast_backmult = c->agc[kAgcFastBackmult], hang_backmult = c->agc[kAgcHangBackmult];
   asm volatile("" : "+v"(fast_backmult), "+v"(hang_backmult));
+#if T41RX_AGC_PHASED
+  float attack_mult_v = gc.attack_mult, min_volts_v = gc.min_volts;
+  asm volatile("" : "+v"(attack_mult_v), "+v"(min_volts_v));  // v_pk_mul / v_max operands: keep them in VGPRs
+#endif
   const int ch = (nvalid == 16) ? (lane & 15) : (lane & 15) % nvalid;  // this lane's channel, as a loader and as a chain
   const int q = lane >> 4;                                              // the float4 of a chunk it moves
   float *gsrc = grp + (size_t)ch * (kPipeSlots * kPipeSlotFloats) + 4 * q;
@@ -1324,6 +1404,61 @@ __device__ __forceinline__ void agc_chain_pipe(float *grp, float *stw0, size_t s
     // by then they have long landed.  (Round 3 took them over at the top of the next block, i.e. waited out an LDS round
     // trip per block behind fifteen other waves' traffic; the request is unconditional -- the last block re-reads its
     // own -- so the registers are not a merge of old and new values.)
+#if T41RX_AGC_PHASED
+    float4 r4 = lds4(sw);
+    float4 keep = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma nounroll
+    for (int b = 0; b < 4; ++b) {
+      // the back-averages' operands of this block: requested now, used behind the four steps
+      const float4 pa4 = lds4(sw + 16 + 8 * b), pb4 = lds4(sw + 16 + 8 * b + 4);
+      // ... and the next block's ring maxima (the last block re-reads its own: unconditional, so nr4 is one value, not a
+      // merge), taken over at the end of the block: four moves, and no LDS round trip between two blocks
+      const float4 nr4 = lds4(sw + 4 * (b < 3 ? b + 1 : 3));
+      const bool has3 = (d.is3 & ~d.in0) != 0;
+      float vo[4];
+      const f2 mult = f2{attack_mult_v, d.stay};
+      AgcState t = st;
+      AgcLane dt = d;
+      lanemask sand = 0;
+      lanemask ok = has3 ? agc_block_phased<true>(t, dt, gc, mult, min_volts_v, r4, pa4, pb4, vo, sand)
+                         : agc_block_phased<false>(t, dt, gc, mult, min_volts_v, r4, pa4, pb4, vo, sand);
+      if ((sand | ~ok) != 0) {  // rare: this block again from the stage, by the forms that have every case
+        const float4 q4 = lds4(sw + 4 * b);
+        const float rm[4] = {q4.x, q4.y, q4.z, q4.w};
+        const float pf[4] = {pa4.x, pa4.z, pb4.x, pb4.z}, ph[4] = {pa4.y, pa4.w, pb4.y, pb4.w};
+        if (sand != 0) {  // a rounding boundary between the bracketing values somewhere: the double expression decides
+          t = st;
+          dt = d;
+          ok = agc_fast_block<true>(t, dt, gc, rm, pf, ph, vo);
+        }
+        if (~ok != 0) {
+#ifdef T41RX_PIPE_STAT
+          acc_slow += 1;
+#endif
+          if (((~ok >> lane) & 1ull) != 0) {
+            t = st;
+            agc_slow_block(t, gc, rm, pf, ph, vo);
+          }
+          dt = agc_lane_of(t, gc);
+        }
+      }
+      st = t;
+      d = dt;
+      // The four lanes of a channel have computed the same four values; the lane whose quarter of the chunk this block is
+      // keeps them for the chunk's store.  (Round 3 wrote them to the stage and read the chunk back: the compiler's wait
+      // for the next block's operands then also waits for that write -- an LDS round trip behind fifteen other waves'
+      // traffic, ~150 cycles, in every block.)
+      {
+        const lanemask mine = 0xffffull << (16 * b);
+        keep.x = pick(mine, vo[0], keep.x);
+        keep.y = pick(mine, vo[1], keep.y);
+        keep.z = pick(mine, vo[2], keep.z);
+        keep.w = pick(mine, vo[3], keep.w);
+      }
+      asm volatile("" : "+v"(vo[3]));  // (the take-over below stays behind the steps)
+      r4 = nr4;
+    }
+#else
     float4 r4 = lds4(sw), pa4 = lds4(sw + 16), pb4 = lds4(sw + 20);
 #pragma nounroll
     for (int b = 0; b < 4; ++b) {
@@ -1353,11 +1488,19 @@ __device__ __forceinline__ void agc_chain_pipe(float *grp, float *stw0, size_t s
       pa4 = npa;
       pb4 = npb;
     }
+#endif
+#if T41RX_AGC_PHASED
+#ifdef T41RX_PIPE_STAT
+    acc_comp += __builtin_readcyclecounter() - ts1;  // the chunk's 16 steps
+#endif
+    *reinterpret_cast<float4 *>(gsrc + kPipeChunk * k) = keep;  // volts in ring_max's place
+#else
     wave_sync();
 #ifdef T41RX_PIPE_STAT
     acc_comp += __builtin_readcyclecounter() - ts1;  // the chunk's 16 steps
 #endif
     *reinterpret_cast<float4 *>(gsrc + kPipeChunk * k) = lds4(sw + 4 * q);  // volts in ring_max's place
+#endif
   }
   if (lane < nvalid) {
     *reinterpret_cast<float4 *>(stw) = make_float4(st.fast_backaverage, st.hang_backaverage, st.volts, st.save_volts);

@@ -856,61 +856,95 @@ __device__ __forceinline__ lanemask agc_block(AgcState &t, AgcLane &dt, const Ag
 #ifndef T41RX_AGC_PHASED
 #define T41RX_AGC_PHASED 1
 #endif
-// (the bookkeeping of a step and the back-averages are written between the steps: they fill the issue slots the dependent
-// chain sub -> mul -> add / fma -> select -> select -> max leaves open; measured with all of it behind the four steps: 1.5 %
-// slower than the unpacked form, the steps then run one instruction per dependency stall)
-template <bool HAS3>
-__device__ __forceinline__ lanemask agc_block_phased(AgcState &st, AgcLane &d, const AgcConsts &g, f2 mult /* (attack_mult, stay) */,
-                                                     float min_volts, const float4 r4, const float4 pa4, const float4 pb4,
+//   * state 3's bracket and the other states' plain sum are ONE operation: fma(ss, c, volts) with c = c_hi for the lanes in
+//     state 3 and c = 1 for the others -- fma(ss, 1, volts) IS fl(volts + ss) -- so a per-lane constant pair (c_lo, c_hi) or
+//     (1, 1) replaces the second packed add, the select by state and the block's dispatch on "some lane is in state 3";
+//   * the masks' bookkeeping is done per block: in the usual block no lane attacks and none is in state 0, nothing about
+//     the states changes, and because volts does not rise in such a block the last step's comparison with the fast decay's
+//     threshold covers all four; otherwise the step-by-step form below it runs (same masks, same order).
+// (The back-averages are written between the steps: they fill issue slots the dependent chain sub -> mul -> fma -> select ->
+// max leaves open.  Timing experiments on one box, 33.6 us per frame: without the back-averages 31.3, without the
+// bookkeeping 30.2, without the bracket 32.0, without all three 29.4 -- the chain is paced by its instruction count.)
+#ifndef T41RX_AGC_X
+#define T41RX_AGC_X 0  // timing experiments (wrong results): 1 no back-averages, 2 no bookkeeping, 4 no bracket
+#endif
+struct AgcLaneP {
+  f2 mult;  // (attack_mult, stay)
+  f2 cb;    // state 3: the second float neighbours of .05 either side (see above); the others: (1, 1)
+};
+__device__ __forceinline__ AgcLaneP agc_lanep_of(const AgcState &st, const AgcLane &d, float attack_mult) {
+  const bool s3 = st.state == 3;
+  AgcLaneP lp;
+  lp.mult = f2{attack_mult, d.stay};
+  lp.cb = f2{s3 ? __uint_as_float(0x3d4ccccbu) : 1.0f, s3 ? __uint_as_float(0x3d4cccceu) : 1.0f};
+  return lp;
+}
+__device__ __forceinline__ lanemask agc_block_phased(AgcState &st, AgcLane &d, const AgcConsts &g, const AgcLaneP &lp, float min_volts,
+                                                     const float4 r4, const float4 a4, f2 backmult /* (fast, hang) */,
                                                      float (&vo)[4], lanemask &sand) {
 #pragma clang fp contract(off)
   const float rm[4] = {r4.x, r4.y, r4.z, r4.w};
-  const f2 pp[4] = {f2{pa4.x, pa4.y}, f2{pa4.z, pa4.w}, f2{pb4.x, pb4.y}, f2{pb4.z, pb4.w}};
-  const f2 cb = f2{__uint_as_float(0x3d4ccccbu), __uint_as_float(0x3d4cccceu)};  // second float neighbours of .05 (see above)
+  const float am[4] = {a4.x, a4.y, a4.z, a4.w};  // |popped|: the back-averages take backmult * |popped| (:525-526)
   const f2 onem = f2{g.onemfast_backmult, g.onemhang_backmult};
-  float volts = st.volts, save_volts = st.save_volts;
+  float volts = st.volts;
   f2 back = f2{st.fast_backaverage, st.hang_backaverage};
-  lanemask ok = ~(d.is2 & __builtin_amdgcn_ballot_w64(st.hang_counter <= 4));  // the hang counter cannot run out inside the block
-  lanemask in0 = d.in0, pend = d.pend, df = 0;
+  lanemask ge[4], df = 0;
+  float vin[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const float vin = volts;
+    vin[k] = volts;
     const float diff = rm[k] - volts;
-    const lanemask ge = lanes_ge(rm[k], volts);
-    const lanemask gt = lanes_gt(volts, d.thr);
-    const f2 s2 = splat(diff) * mult;   // (diff * attack_mult, diff * stay)
-    const f2 n2 = splat(volts) + s2;    // (attack candidate, stay candidate)
-    float cand = n2.y;
-    if (HAS3) {
-      const f2 r = pk_fma(splat(s2.y), cb, splat(volts));
+    ge[k] = lanes_ge(rm[k], volts);
+    const f2 s2 = splat(diff) * lp.mult;  // (diff * attack_mult, diff * stay)
+    const float na = volts + s2.x;        // the attack's value
+    float cand;
+    if (!(T41RX_AGC_X & 4)) {
+      const f2 r = pk_fma(splat(s2.y), lp.cb, splat(volts));  // state 3: the bracket; the others: volts + ss twice
       lanemask differ;
       asm("v_cmp_neq_f32_e64 %0, %1, %2" : "=s"(differ) : "v"(r.x), "v"(r.y));
       df |= differ;
-      cand = pick(d.is3, r.y, cand);
+      cand = r.y;
+    } else {
+      cand = volts + s2.y;
     }
-    const float next = pick(ge, n2.x, cand);
+    const float next = pick(ge[k], na, cand);
     asm("v_max_f32 %0, %1, %2" : "=v"(volts) : "v"(next), "v"(min_volts));  // :629 (no NaNs here)
     vo[k] = volts;
-    // the step's bookkeeping and (two steps behind: their operands were requested at the top of the block) the back-averages
-    ok &= ge | (gt & ~in0);
-    save_volts = pick(ge & pend, vin, save_volts);  // the first attack out of 2, 3, 4
-    pend &= ~ge;
-    in0 |= ge;
-    if (k >= 2) {
-      back = pp[2 * (k - 2)] + onem * back;  // :525-526
-      back = pp[2 * (k - 2) + 1] + onem * back;
+    if (k >= 2 && !(T41RX_AGC_X & 1)) {  // two steps behind: their operands were requested at the top of the block
+      back = splat(am[2 * (k - 2)]) * backmult + onem * back;  // :525-526
+      back = splat(am[2 * (k - 2) + 1]) * backmult + onem * back;
     }
   }
-  sand = HAS3 ? (df & d.is3) : 0;
+  lanemask ok = ~(d.is2 & __builtin_amdgcn_ballot_w64(st.hang_counter <= 4));  // the hang counter cannot run out inside the block
+  if (!(T41RX_AGC_X & 2)) {
+    const lanemask any = ge[0] | ge[1] | ge[2] | ge[3];
+    if (__builtin_expect((any | d.in0) == 0, 1)) {
+      // no attack, no lane in state 0: every lane stays in its decay state unless its fast decay has reached save_volts --
+      // volts does not rise without an attack (diff < 0, multipliers >= 0, monotonic roundings), so "volts > thr" before
+      // the last step implies it before the three others
+      ok &= lanes_gt(vin[3], d.thr);
+    } else {
+      lanemask in0 = d.in0, pend = d.pend;
+      float save_volts = st.save_volts;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        ok &= ge[k] | (lanes_gt(vin[k], d.thr) & ~in0);
+        save_volts = pick(ge[k] & pend, vin[k], save_volts);  // the first attack out of 2, 3, 4
+        pend &= ~ge[k];
+        in0 |= ge[k];
+      }
+      st.save_volts = save_volts;
+      st.state = __float_as_int(pick(in0, __int_as_float(0), __int_as_float(st.state)));
+      d.pend = pend;
+      d.in0 = in0;
+    }
+  }
+  sand = df;
   st.fast_backaverage = back.x;
   st.hang_backaverage = back.y;
   st.volts = volts;
-  st.save_volts = save_volts;
-  st.state = __float_as_int(pick(in0, __int_as_float(0), __int_as_float(st.state)));
   const int hc = st.hang_counter - 4;
   st.hang_counter = hc > 0 ? hc : 0;
-  d.pend = pend;
-  d.in0 = in0;
   return ok;
 }
 
@@ -1316,6 +1350,173 @@ constexpr int kPipeStageFloats = 16 * kPipeChStride;
 #ifndef T41RX_PIPE_AHEAD
 #define T41RX_PIPE_AHEAD 2  // chunks requested ahead (measured: 1, 2, 3, 4 within 1 %; 6 spills and is 23 % slower)
 #endif
+#if T41RX_AGC_PHASED
+// Round 4: the chunk's operands are staged ONE CHUNK AHEAD into the other half of a double buffer (ring maxima and the raw
+// |popped| -- 36 floats per channel and half instead of 52 with the two products, which the chain forms itself: one
+// v_pk_mul_f32 per step, off the dependent path), so no block waits for an LDS write -> read round trip any more (the first
+// block of every chunk did, ~185 cycles behind fifteen other waves' LDS traffic); the chunk's volts never touch the stage
+// (see `keep`).  Chunk k + 1 is written at the top of chunk k and read a chunk later: the LDS unit executes one wave's
+// instructions in order, the compiler is held by wave_sync().
+constexpr int kPipeChStrideP = 36;                      // ring_max [16] | |popped| [16] | 4 pad (conflict-free float4 rows)
+constexpr int kPipeHalfFloats = 16 * kPipeChStrideP;
+static_assert(2 * kPipeHalfFloats <= 1268, "double-buffered chain stage inside the X scratch");
+__device__ __forceinline__ void agc_chain_pipe(float *grp, float *stw0, size_t stride, float *stage, const unsigned *done, unsigned g,
+                                               int nvalid, CoefPtr cf0, int lane, unsigned long long *pipe_stat, unsigned *err) {
+  const CoefPtr c = fresh_coef(cf0);
+  AgcConsts gc;
+  gc.attack_mult = c->agc[kAgcAttackMult];
+  gc.decay_mult = c->agc[kAgcDecayMult];
+  gc.fast_decay_mult = c->agc[kAgcFastDecayMult];
+  gc.hang_decay_mult = c->agc[kAgcHangDecayMult];
+  gc.onemfast_backmult = c->agc[kAgcOnemFastBackmult];
+  gc.onemhang_backmult = c->agc[kAgcOnemHangBackmult];
+  gc.min_volts = c->agc[kAgcMinVolts];
+  gc.hang_level = c->agc[kAgcHangLevel];
+  gc.pop_ratio = c->agc[kAgcPopRatio];
+  gc.hang_count = (int)c->agc[kAgcHangCount];
+  float fast_backmult = c->agc[kAgcFastBackmult], hang_backmult = c->agc[kAgcHangBackmult];
+  float attack_mult_v = gc.attack_mult, min_volts_v = gc.min_volts;
+  asm volatile("" : "+v"(fast_backmult), "+v"(hang_backmult), "+v"(attack_mult_v), "+v"(min_volts_v));  // VOP3P / v_max operands: VGPRs
+  const f2 backmult = f2{fast_backmult, hang_backmult};
+  const int ch = (nvalid == 16) ? (lane & 15) : (lane & 15) % nvalid;  // this lane's channel, as a loader and as a chain
+  const int q = lane >> 4;                                              // the float4 of a chunk it moves
+  float *gsrc = grp + (size_t)ch * (kPipeSlots * kPipeSlotFloats) + 4 * q;
+  float *sw0 = stage + ch * kPipeChStrideP;
+  constexpr int NCH = 256 / kPipeChunk;
+  // chunks 0 and 1 requested before the wait for the previous frame's chain; from then on chunk k + 3 at the top of chunk k
+  float4 pr0 = *reinterpret_cast<const float4 *>(gsrc), pa0 = *reinterpret_cast<const float4 *>(gsrc + 256);
+  float4 pr1 = *reinterpret_cast<const float4 *>(gsrc + kPipeChunk), pa1 = *reinterpret_cast<const float4 *>(gsrc + 256 + kPipeChunk);
+  {
+    PIPE_STAT_T0();
+    pipe_wait_ge(done, g, err);  // the previous frame's chain has left the state words
+    PIPE_STAT_ADD(4);
+  }
+  PIPE_STAT_T0();
+  float *stw = stw0 + (size_t)ch * stride;
+  const float4 sf = *reinterpret_cast<const float4 *>(stw);
+  const int4 si = *reinterpret_cast<const int4 *>(stw + 4);
+  wave_sync();
+  *reinterpret_cast<float4 *>(sw0 + 4 * q) = pr0;  // chunk 0 -> half 0
+  *reinterpret_cast<float4 *>(sw0 + 16 + 4 * q) = pa0;
+  pr0 = pr1;
+  pa0 = pa1;
+  pr1 = *reinterpret_cast<const float4 *>(gsrc + kPipeChunk * 2);
+  pa1 = *reinterpret_cast<const float4 *>(gsrc + 256 + kPipeChunk * 2);
+  wave_sync();
+#ifdef T41RX_PIPE_STAT
+  asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  if (lane == 0) pipe_stat[12] += __builtin_readcyclecounter() - pipe_t0;  // the state words' (and every older request's) round trip
+  unsigned long long acc_stage = 0, acc_comp = 0, acc_slow = 0;
+#endif
+  AgcState st{sf.x, sf.y, sf.z, sf.w, si.x, si.y, si.z};
+  AgcLane d = agc_lane_of(st, gc);
+  AgcLaneP lp = agc_lanep_of(st, d, attack_mult_v);
+  float4 r4 = lds4(sw0);  // chunk 0's first ring maxima; from then on every block requests its successor's
+  // (rolled loops: one copy of the four-step block instead of sixteen; the register ring of requested chunks rotates by
+  // moves.  Measured in round 3: the inner loop unrolled, four copies, runs 12 % faster per step and the kernel 6 % slower
+  // (two copies: 1.5 % slower) -- the other waves' front and back ends share the instruction cache)
+#pragma nounroll
+  for (int k = 0; k < NCH; ++k) {
+    float *sw = sw0 + (k & 1) * kPipeHalfFloats;
+    {
+#ifdef T41RX_PIPE_STAT
+      const unsigned long long ts0 = __builtin_readcyclecounter();
+#endif
+      // chunk k + 1 -> the other half (read from the top of the next iteration on); chunk k + 3 requested into the freed
+      // registers (clamped: the last iterations re-read chunk 15, whose volts are stored after they have read it -- the
+      // request is unconditional so that the registers are one value, not a merge)
+      const float4 r4n = pr0, a4n = pa0;
+      pr0 = pr1;
+      pa0 = pa1;
+      {
+        const int kn = k + 3 < NCH ? k + 3 : NCH - 1;
+        pr1 = *reinterpret_cast<const float4 *>(gsrc + kPipeChunk * kn);
+        pa1 = *reinterpret_cast<const float4 *>(gsrc + 256 + kPipeChunk * kn);
+      }
+      wave_sync();
+      if (k + 1 < NCH) {
+        float *swn = sw0 + ((k + 1) & 1) * kPipeHalfFloats;
+        *reinterpret_cast<float4 *>(swn + 4 * q) = r4n;
+        *reinterpret_cast<float4 *>(swn + 16 + 4 * q) = a4n;
+      }
+      wave_sync();
+#ifdef T41RX_PIPE_STAT
+      acc_stage += __builtin_readcyclecounter() - ts0;  // staging the next chunk's operands
+#endif
+    }
+#ifdef T41RX_PIPE_STAT
+    const unsigned long long ts1 = __builtin_readcyclecounter();
+#endif
+    float4 keep = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma nounroll
+    for (int b = 0; b < 4; ++b) {
+      // the back-averages' operands of this block: requested now, used two steps further down; and the next block's ring
+      // maxima -- the chunk's last block requests the NEXT chunk's first ones from the other half (the last chunk reads
+      // whatever is there: unconditional, so nr4 is one value, not a merge) --, taken over at the end of the block: four
+      // moves, and no LDS round trip between two blocks or two chunks
+      const float4 a4 = lds4(sw + 16 + 4 * b);
+      const float4 nr4 = lds4(b < 3 ? sw + 4 * (b + 1) : sw0 + ((k + 1) & 1) * kPipeHalfFloats);
+      float vo[4];
+      AgcState t = st;
+      AgcLane dt = d;
+      lanemask sand = 0;
+      lanemask ok = agc_block_phased(t, dt, gc, lp, min_volts_v, r4, a4, backmult, vo, sand);
+      if ((sand | ~ok) != 0) {  // rare: this block again, by the forms that have every case
+#pragma clang fp contract(off)
+        const float rm[4] = {r4.x, r4.y, r4.z, r4.w};
+        const float pf[4] = {fast_backmult * a4.x, fast_backmult * a4.y, fast_backmult * a4.z, fast_backmult * a4.w};
+        const float ph[4] = {hang_backmult * a4.x, hang_backmult * a4.y, hang_backmult * a4.z, hang_backmult * a4.w};
+        if (sand != 0) {  // a rounding boundary between the bracketing values somewhere: the double expression decides
+          t = st;
+          dt = d;
+          ok = agc_fast_block<true>(t, dt, gc, rm, pf, ph, vo);
+        }
+        if (~ok != 0) {
+#ifdef T41RX_PIPE_STAT
+          acc_slow += 1;
+#endif
+          if (((~ok >> lane) & 1ull) != 0) {
+            t = st;
+            agc_slow_block(t, gc, rm, pf, ph, vo);
+          }
+          dt = agc_lane_of(t, gc);
+          lp = agc_lanep_of(t, dt, attack_mult_v);
+        }
+      }
+      st = t;
+      d = dt;
+      // The four lanes of a channel have computed the same four values; the lane whose quarter of the chunk this block is
+      // keeps them for the chunk's store.  (Round 3 wrote them to the stage and read the chunk back: the compiler's wait
+      // for the next block's operands then also waited for that write -- an LDS round trip, ~150 cycles, in every block.)
+      {
+        const lanemask mine = 0xffffull << (16 * b);
+        keep.x = pick(mine, vo[0], keep.x);
+        keep.y = pick(mine, vo[1], keep.y);
+        keep.z = pick(mine, vo[2], keep.z);
+        keep.w = pick(mine, vo[3], keep.w);
+      }
+      asm volatile("" : "+v"(vo[3]));  // (the take-over below stays behind the steps)
+      r4 = nr4;
+    }
+#ifdef T41RX_PIPE_STAT
+    acc_comp += __builtin_readcyclecounter() - ts1;  // the chunk's 16 steps
+#endif
+    *reinterpret_cast<float4 *>(gsrc + kPipeChunk * k) = keep;  // volts in ring_max's place
+  }
+  if (lane < nvalid) {
+    *reinterpret_cast<float4 *>(stw) = make_float4(st.fast_backaverage, st.hang_backaverage, st.volts, st.save_volts);
+    *reinterpret_cast<int4 *>(stw + 4) = make_int4(st.state, st.decay_type, st.hang_counter, 0);
+  }
+  PIPE_STAT_ADD(0);
+  PIPE_STAT_INC(1, 1);
+  PIPE_STAT_INC(5, 64);
+#ifdef T41RX_PIPE_STAT
+  PIPE_STAT_INC(2, acc_slow);
+  PIPE_STAT_INC(6, acc_stage);
+  PIPE_STAT_INC(7, acc_comp);
+#endif
+}
+#else
 __device__ __forceinline__ void agc_chain_pipe(float *grp, float *stw0, size_t stride, float *stage, const unsigned *done, unsigned g,
                                                int nvalid, CoefPtr cf0, int lane, unsigned long long *pipe_stat, unsigned *err) {
   const CoefPtr c = fresh_coef(cf0);
@@ -1332,10 +1533,6 @@ __device__ __forceinline__ void agc_chain_pipe(float *grp, float *stw0, size_t s
   gc.hang_count = (int)c->agc[kAgcHangCount];
   float fast_backmult = c->agc[kAgcFastBackmult], hang_backmult = c->agc[kAgcHangBackmult];
   asm volatile("" : "+v"(fast_backmult), "+v"(hang_backmult));
-#if T41RX_AGC_PHASED
-  float attack_mult_v = gc.attack_mult, min_volts_v = gc.min_volts;
-  asm volatile("" : "+v"(attack_mult_v), "+v"(min_volts_v));  // v_pk_mul / v_max operands: keep them in VGPRs
-#endif
   const int ch = (nvalid == 16) ? (lane & 15) : (lane & 15) % nvalid;  // this lane's channel, as a loader and as a chain
   const int q = lane >> 4;                                              // the float4 of a chunk it moves
   float *gsrc = grp + (size_t)ch * (kPipeSlots * kPipeSlotFloats) + 4 * q;
@@ -1404,61 +1601,6 @@ __device__ __forceinline__ void agc_chain_pipe(float *grp, float *stw0, size_t s
     // by then they have long landed.  (Round 3 took them over at the top of the next block, i.e. waited out an LDS round
     // trip per block behind fifteen other waves' traffic; the request is unconditional -- the last block re-reads its
     // own -- so the registers are not a merge of old and new values.)
-#if T41RX_AGC_PHASED
-    float4 r4 = lds4(sw);
-    float4 keep = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma nounroll
-    for (int b = 0; b < 4; ++b) {
-      // the back-averages' operands of this block: requested now, used behind the four steps
-      const float4 pa4 = lds4(sw + 16 + 8 * b), pb4 = lds4(sw + 16 + 8 * b + 4);
-      // ... and the next block's ring maxima (the last block re-reads its own: unconditional, so nr4 is one value, not a
-      // merge), taken over at the end of the block: four moves, and no LDS round trip between two blocks
-      const float4 nr4 = lds4(sw + 4 * (b < 3 ? b + 1 : 3));
-      const bool has3 = (d.is3 & ~d.in0) != 0;
-      float vo[4];
-      const f2 mult = f2{attack_mult_v, d.stay};
-      AgcState t = st;
-      AgcLane dt = d;
-      lanemask sand = 0;
-      lanemask ok = has3 ? agc_block_phased<true>(t, dt, gc, mult, min_volts_v, r4, pa4, pb4, vo, sand)
-                         : agc_block_phased<false>(t, dt, gc, mult, min_volts_v, r4, pa4, pb4, vo, sand);
-      if ((sand | ~ok) != 0) {  // rare: this block again from the stage, by the forms that have every case
-        const float4 q4 = lds4(sw + 4 * b);
-        const float rm[4] = {q4.x, q4.y, q4.z, q4.w};
-        const float pf[4] = {pa4.x, pa4.z, pb4.x, pb4.z}, ph[4] = {pa4.y, pa4.w, pb4.y, pb4.w};
-        if (sand != 0) {  // a rounding boundary between the bracketing values somewhere: the double expression decides
-          t = st;
-          dt = d;
-          ok = agc_fast_block<true>(t, dt, gc, rm, pf, ph, vo);
-        }
-        if (~ok != 0) {
-#ifdef T41RX_PIPE_STAT
-          acc_slow += 1;
-#endif
-          if (((~ok >> lane) & 1ull) != 0) {
-            t = st;
-            agc_slow_block(t, gc, rm, pf, ph, vo);
-          }
-          dt = agc_lane_of(t, gc);
-        }
-      }
-      st = t;
-      d = dt;
-      // The four lanes of a channel have computed the same four values; the lane whose quarter of the chunk this block is
-      // keeps them for the chunk's store.  (Round 3 wrote them to the stage and read the chunk back: the compiler's wait
-      // for the next block's operands then also waits for that write -- an LDS round trip behind fifteen other waves'
-      // traffic, ~150 cycles, in every block.)
-      {
-        const lanemask mine = 0xffffull << (16 * b);
-        keep.x = pick(mine, vo[0], keep.x);
-        keep.y = pick(mine, vo[1], keep.y);
-        keep.z = pick(mine, vo[2], keep.z);
-        keep.w = pick(mine, vo[3], keep.w);
-      }
-      asm volatile("" : "+v"(vo[3]));  // (the take-over below stays behind the steps)
-      r4 = nr4;
-    }
-#else
     float4 r4 = lds4(sw), pa4 = lds4(sw + 16), pb4 = lds4(sw + 20);
 #pragma nounroll
     for (int b = 0; b < 4; ++b) {
@@ -1488,19 +1630,11 @@ __device__ __forceinline__ void agc_chain_pipe(float *grp, float *stw0, size_t s
       pa4 = npa;
       pb4 = npb;
     }
-#endif
-#if T41RX_AGC_PHASED
-#ifdef T41RX_PIPE_STAT
-    acc_comp += __builtin_readcyclecounter() - ts1;  // the chunk's 16 steps
-#endif
-    *reinterpret_cast<float4 *>(gsrc + kPipeChunk * k) = keep;  // volts in ring_max's place
-#else
     wave_sync();
 #ifdef T41RX_PIPE_STAT
     acc_comp += __builtin_readcyclecounter() - ts1;  // the chunk's 16 steps
 #endif
     *reinterpret_cast<float4 *>(gsrc + kPipeChunk * k) = lds4(sw + 4 * q);  // volts in ring_max's place
-#endif
   }
   if (lane < nvalid) {
     *reinterpret_cast<float4 *>(stw) = make_float4(st.fast_backaverage, st.hang_backaverage, st.volts, st.save_volts);
@@ -1515,6 +1649,8 @@ __device__ __forceinline__ void agc_chain_pipe(float *grp, float *stw0, size_t s
   PIPE_STAT_INC(7, acc_comp);
 #endif
 }
+
+#endif
 
 // last part of agc_apply: og[k] = popped sample 4 lane + k times the gain from volts
 struct AgcGainIn { float4 vv, zr, zi; };  // requested ahead of the AGC preparation of the front end's frame, which hides the round trip

@@ -838,33 +838,34 @@ __device__ __forceinline__ lanemask agc_block(AgcState &t, AgcLane &dt, const Ag
 #endif
 }
 
-// Round 4, second step: agc_fast_block_s() in three phases for agc_chain_pipe(), whose wave issues one instruction per
-// ~4-5 cycles whatever it is -- what paces the chain is the COUNT of instructions per block (150 in the form above: 122 in
-// the block, the rest moves), so this form exists to have fewer:
-//   * the two candidates of a step as packed pairs: (diff, diff) x (attack_mult, stay) is one v_pk_mul_f32, volts + both
-//     products one v_pk_add_f32, the bracketing pair of state 3 one v_pk_fma_f32 with (c_lo, c_hi) -- the same products,
-//     sums and FMAs on the same values, three instructions instead of six per step;
-//   * the steps need the four ring maxima only, so the back-averages' operands are requested at the top of the block they
-//     belong to and used two steps later, and only the NEXT block's ring maxima ride in prefetch registers: 4 moves per
-//     block instead of 12.  (Reading them at the block's end into the registers the steps have just finished with -- no
-//     move at all -- exposes an LDS round trip per block behind fifteen other waves' traffic: measured, no gain);
-//   * the bracket's verdict is taken per block: (df0 | df1 | df2 | df3) & is3 instead of a mask expression per step (a
-//     lane that attacked at the one step in ten thousand where its bracket stayed open takes the double-precision
-//     block although it would not have had to: same values).
-// Every float operation is one of agc_fast_block_s()'s on the same operands: bit-identical (T41RX_AGC_PHASED=0 builds the
-// form above; tools/agc_decay_check.py, the pipelined == barrier tests and tools/pipe_soak.py compare them).
+// Round 4, second step: the block of agc_chain_pipe().  The duty wave issues one instruction per ~5-6 cycles whatever it
+// is, so what paces the chain is the COUNT of instructions per block (150 with agc_fast_block_s(): 122 in the block, the
+// rest moves) and every LDS round trip the compiler's waits expose (~150-185 cycles each behind fifteen other waves'
+// traffic).  This form has ~100 instructions per block and no exposed round trip:
+//   * the attack's and the stay's products are one v_pk_mul_f32: (diff, diff) x (attack_mult, stay);
+//   * state 3's bracket and the other states' plain sum are ONE operation: fma(ss, c, volts) with c = c_hi for the lanes in
+//     state 3 and c = 1 for the others -- fma(ss, 1, volts) IS fl(volts + ss) -- so a per-lane constant pair (c_lo, c_hi) or
+//     (1, 1) makes both bracketing values one v_pk_fma_f32 for every lane, and the select by state, the second sum and
+//     the block's dispatch on "some lane is in state 3" are gone (for the other lanes the two halves are equal by
+//     construction, so the bracket's verdict needs no mask either: df0 | df1 | df2 | df3);
+//   * the masks' bookkeeping is done per block: in the usual block no lane attacks and none is in state 0, nothing about
+//     the states changes, and because volts does not rise in such a block the last step's comparison with the fast decay's
+//     threshold covers all four; otherwise the step-by-step form below it runs (same masks, same order);
+//   * the steps need the four ring maxima only: the NEXT block's (the next chunk's first, from the other half of the
+//     double-buffered stage) are requested at the top of a block and taken over at its end, four moves; the back-averages'
+//     operands are requested at the top of the block they belong to and used behind its steps.  (Reading the ring maxima at
+//     the block's end into the registers the steps have just finished with -- no move at all -- exposes an LDS round trip
+//     per block: measured, no gain);
+//   * the chunk's volts stay in registers (agc_chain_pipe: `keep`) instead of a write to the stage and a read back.
+// Every float operation is one of agc_fast_block_s()'s on the same operands, or an FMA by 1 in place of a sum: bit-identical
+// (T41RX_AGC_PHASED=0 builds the form above; tools/agc_decay_check.py, the pipelined == barrier tests and
+// tools/pipe_soak.py -- 89 529 random runs, profiles/r04_pipe_soak2.json -- compare them).
+// Timing experiments on one box (wrong results, T41RX_AGC_X), before the bookkeeping went per block, 33.6 us per frame:
+// without the back-averages 31.3, without the bookkeeping 30.2, without the bracket 32.0, without all three 29.4; after:
+// 30.2 -> 29.9 / 29.5 / 29.7 / 28.8 -- what is left of the period is the sixteen waves' own work.
 #ifndef T41RX_AGC_PHASED
 #define T41RX_AGC_PHASED 1
 #endif
-//   * state 3's bracket and the other states' plain sum are ONE operation: fma(ss, c, volts) with c = c_hi for the lanes in
-//     state 3 and c = 1 for the others -- fma(ss, 1, volts) IS fl(volts + ss) -- so a per-lane constant pair (c_lo, c_hi) or
-//     (1, 1) replaces the second packed add, the select by state and the block's dispatch on "some lane is in state 3";
-//   * the masks' bookkeeping is done per block: in the usual block no lane attacks and none is in state 0, nothing about
-//     the states changes, and because volts does not rise in such a block the last step's comparison with the fast decay's
-//     threshold covers all four; otherwise the step-by-step form below it runs (same masks, same order).
-// (The back-averages are written between the steps: they fill issue slots the dependent chain sub -> mul -> fma -> select ->
-// max leaves open.  Timing experiments on one box, 33.6 us per frame: without the back-averages 31.3, without the
-// bookkeeping 30.2, without the bracket 32.0, without all three 29.4 -- the chain is paced by its instruction count.)
 #ifndef T41RX_AGC_X
 #define T41RX_AGC_X 0  // timing experiments (wrong results): 1 no back-averages, 2 no bookkeeping, 4 no bracket
 #endif
@@ -1000,6 +1001,9 @@ __device__ __forceinline__ float sam_atan2(float y, float x) {  // ApproxAtan2, 
 // of the NEXT step (index arithmetic, four table reads, two interpolations) are evaluated while this step's
 // products, arctangent (an IEEE division) and loop filter run: two independent dependency chains per iteration
 // instead of one twice as long.  Same operations on the same values as the loop as written.
+#ifndef T41RX_SAM_DEFER
+#define T41RX_SAM_DEFER 1  // 0: the compiler's own placement of the interpolation (A/B)
+#endif
 struct SamPll {
   const float *T;  // arm_sin_f32's table (LDS)
   float omega_min, omega_max, g1, g2;
@@ -1026,8 +1030,14 @@ struct SamPll {
     // (the source's two `while` loops: |del_out| <= g1 (2 pi + pi / 4) + omega_max < 1.2, so one pass each)
     if (phznext >= kTpi) phznext -= kTpi;
     if (phznext < 0.0f) phznext += kTpi;
-    float SinN, CosN;
-    sincos(phznext, SinN, CosN);
+    // The next step's table entries are REQUESTED here and interpolated behind this step's detector (round 4): the
+    // interpolation right behind the request, as the compiler places it when left alone, waits out an LDS round trip in
+    // every step -- the longest single item of a step on the duty wave, whose fifteen neighbours keep the LDS pipe busy.
+    const SamIdx is = sam_table_index_pos(phznext * 0.159154943092f), ic = sam_table_index_pos(phznext * 0.159154943092f + 0.25f);
+    const float sa = T[is.index], sb = T[is.index + 1], ca = T[ic.index], cb = T[ic.index + 1];
+#if T41RX_SAM_DEFER
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     const float ai = Cos * z.x, bi = Sin * z.x, aq = Cos * z.y, bq = Sin * z.y;
     const float corr0 = +ai + bq, corr1 = -bi + aq;
     const float audio = (ai - bi) + (aq + bq);
@@ -1036,8 +1046,11 @@ struct SamPll {
     omega2 = __builtin_amdgcn_fmed3f(omega2, omega_min, omega_max);  // Demod.cpp's if / else-if clamp (omega_min < omega_max, no NaNs): one instruction, no branches
     fil_out = g1 * det + omega2;
     phzerror = phznext;
-    Sin = SinN;
-    Cos = CosN;
+#if T41RX_SAM_DEFER
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    Sin = (1.0f - is.fract) * sa + is.fract * sb;  // sincos(phznext), second half
+    Cos = (1.0f - ic.fract) * ca + ic.fract * cb;
     return audio;
   }
   __device__ __forceinline__ void store(float *ms) const {
@@ -1345,8 +1358,13 @@ __device__ __forceinline__ float4 agc_prep_pipe(const cf (&v)[8], float4 agst, f
 //   grp   : slot (frame g) of the workgroup's first channel; channel c's is kPipeSlots * kPipeSlotFloats * c further
 //   stw0  : the eight state words of the workgroup's first channel, channel c's stride floats further
 //   stage : kPipeStageFloats of LDS
-constexpr int kPipeChunk = 16, kPipeChStride = 52;  // per channel in the stage: ring_max -> volts [16] | (b x) pairs [32] | 4 pad
-constexpr int kPipeStageFloats = 16 * kPipeChStride;
+constexpr int kPipeChunk = 16, kPipeChStride = 52;  // (T41RX_AGC_PHASED=0) per channel in the stage: ring_max -> volts [16] | (b x) pairs [32] | 4 pad
+constexpr int kPipeChStrideP = 36;                  // per channel and half: ring_max [16] | |popped| [16] | 4 pad (conflict-free float4 rows)
+constexpr int kPipeHalfFloats = 16 * kPipeChStrideP;
+#ifndef T41RX_AGC_PHASED
+#define T41RX_AGC_PHASED 1
+#endif
+constexpr int kPipeStageFloats = T41RX_AGC_PHASED ? 2 * kPipeHalfFloats : 16 * kPipeChStride;
 #ifndef T41RX_PIPE_AHEAD
 #define T41RX_PIPE_AHEAD 2  // chunks requested ahead (measured: 1, 2, 3, 4 within 1 %; 6 spills and is 23 % slower)
 #endif
@@ -1357,9 +1375,6 @@ constexpr int kPipeStageFloats = 16 * kPipeChStride;
 // block of every chunk did, ~185 cycles behind fifteen other waves' LDS traffic); the chunk's volts never touch the stage
 // (see `keep`).  Chunk k + 1 is written at the top of chunk k and read a chunk later: the LDS unit executes one wave's
 // instructions in order, the compiler is held by wave_sync().
-constexpr int kPipeChStrideP = 36;                      // ring_max [16] | |popped| [16] | 4 pad (conflict-free float4 rows)
-constexpr int kPipeHalfFloats = 16 * kPipeChStrideP;
-static_assert(2 * kPipeHalfFloats <= 1268, "double-buffered chain stage inside the X scratch");
 __device__ __forceinline__ void agc_chain_pipe(float *grp, float *stw0, size_t stride, float *stage, const unsigned *done, unsigned g,
                                                int nvalid, CoefPtr cf0, int lane, unsigned long long *pipe_stat, unsigned *err) {
   const CoefPtr c = fresh_coef(cf0);

@@ -1476,7 +1476,7 @@ __device__ __forceinline__ void agc_chain_pipe(float *grp, float *stw0, size_t s
       AgcLane dt = d;
       lanemask sand = 0;
       lanemask ok = agc_block_phased(t, dt, gc, lp, min_volts_v, r4, a4, backmult, vo, sand);
-      if ((sand | ~ok) != 0) {  // rare: this block again, by the forms that have every case
+      if (__builtin_expect((sand | ~ok) != 0, 0)) {  // rare: this block again, by the forms that have every case
 #pragma clang fp contract(off)
         const float rm[4] = {r4.x, r4.y, r4.z, r4.w};
         const float pf[4] = {fast_backmult * a4.x, fast_backmult * a4.y, fast_backmult * a4.z, fast_backmult * a4.w};

@@ -181,7 +181,18 @@ __device__ __forceinline__ void anr_pass_sigma(const float *T, float *SIG, int l
   }
 }
 
-__global__ __launch_bounds__(128, 1) void anr_kernel(const NrArgs a) {
+__global__ __launch_bounds__(128, 2) void anr_kernel(const NrArgs a) {
+  // (The copy / scale loops below are kept rolled: fully unrolled, with every address hoisted out of the frame loop, they
+  // took the kernel to 353 VGPRs; 161 now.  Measured at the end of round 4, all bit-identical to this form
+  // (tools/anr_ab_check.py) and none faster than 1 %: no workgroup barrier per sample -- sigma through two slots guarded
+  // by LDS counters, wave 1 up to two samples ahead --, the next sample's window and this sample's sigma requested a
+  // chain ahead of their use, both outcomes of the leak logic formed off the path and selected, the window read through
+  // one lane-dependent base with immediate offsets (8 ds_read2_b32 instead of 16 address computations and 16 reads), the
+  // first sample's "no pending update" as a compile-time case (16 selects per sample fewer): 187 -> 165 instructions per
+  // sample, 138 us per frame either way.  Timing experiments: 16 instead of 64 additions per chain -25 us (4.5 cycles
+  // per addition), no leak decision -5, no sigma wave -6.  A sample is ONE dependent sequence -- update, product, 64
+  // additions, 5 lane swaps, error, two double-precision expressions, select, update -- on one wave; what it costs is that
+  // sequence's latency, ~1000 cycles, and neither the instruction count nor the synchronisation.)
 #pragma clang fp contract(off)
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float *T = sm, *O = sm + kAnrTile * kAnrRow, *SIG = sm + kAnrSigOff;  // (16-byte aligned)
@@ -198,18 +209,20 @@ __global__ __launch_bounds__(128, 1) void anr_kernel(const NrArgs a) {
 #pragma unroll
     for (int t = 0; t < 8; ++t)
       w[t] = f2{a.anr[(size_t)(kAnrStW + tb + 2 * t + 1) * nch + ch], a.anr[(size_t)(kAnrStW + tb + 2 * t) * nch + ch]};
-    for (int r = g; r < kAnrHist; r += 4) T[r * kAnrRow + c] = a.anr[(size_t)(kAnrStHist + r) * nch + ch];
+    _Pragma("unroll 4") for (int r = g; r < kAnrHist; r += 4) T[r * kAnrRow + c] = a.anr[(size_t)(kAnrStHist + r) * nch + ch];
     lidx = a.anr[(size_t)kAnrStLidx * nch + ch], ngamma = a.anr[(size_t)kAnrStNgamma * nch + ch];
   }
   for (int f = 0; f < a.nframes; ++f) {
     // stage the frame in: column cc of the tile = channel ch0 + cc, 256 consecutive samples, 4 x 256 B per channel (the
     // two waves take alternate channels)
     __syncthreads();
+_Pragma("nounroll")
     for (int cc = wv; cc < nlive; cc += 2) {
       const float *src = a.aud + ((size_t)(ch0 + cc) * a.nframes + f) * 256;
 #pragma unroll
       for (int q = 0; q < 4; ++q) T[(kAnrHist + lane + 64 * q) * kAnrRow + cc] = src[lane + 64 * q];
     }
+_Pragma("nounroll")
     for (int cc = nlive + ((nlive ^ wv) & 1); cc < kAnrCw; cc += 2) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) T[(kAnrHist + lane + 64 * q) * kAnrRow + cc] = 0.0f;
@@ -222,11 +235,11 @@ __global__ __launch_bounds__(128, 1) void anr_kernel(const NrArgs a) {
       if (wv == 0) {
         if (a.notch) {
           // the notch pass sees the scaled block behind the unscaled one: its delay line = the last 79 unscaled samples
-          for (int r = g; r < kAnrHist; r += 4) T[r * kAnrRow + c] = T[(256 + r) * kAnrRow + c];
+          _Pragma("unroll 4") for (int r = g; r < kAnrHist; r += 4) T[r * kAnrRow + c] = T[(256 + r) * kAnrRow + c];
           __builtin_amdgcn_wave_barrier();
-          for (int i = g; i < 256; i += 4) T[(kAnrHist + i) * kAnrRow + c] = T[(kAnrHist + i) * kAnrRow + c] * 1.5f;
+          _Pragma("unroll 4") for (int i = g; i < 256; i += 4) T[(kAnrHist + i) * kAnrRow + c] = T[(kAnrHist + i) * kAnrRow + c] * 1.5f;
         } else {
-          for (int i = g; i < 256; i += 4) O[i * kAnrRow + c] = T[(kAnrHist + i) * kAnrRow + c] * 1.5f;
+          _Pragma("unroll 4") for (int i = g; i < 256; i += 4) O[i * kAnrRow + c] = T[(kAnrHist + i) * kAnrRow + c] * 1.5f;
         }
       }
       __syncthreads();
@@ -238,8 +251,9 @@ __global__ __launch_bounds__(128, 1) void anr_kernel(const NrArgs a) {
     }
     // the delay line's live part for the next block
     if (wv == 0)
-      for (int r = g; r < kAnrHist; r += 4) T[r * kAnrRow + c] = T[(256 + r) * kAnrRow + c];
+      _Pragma("unroll 4") for (int r = g; r < kAnrHist; r += 4) T[r * kAnrRow + c] = T[(256 + r) * kAnrRow + c];
     __syncthreads();
+_Pragma("nounroll")
     for (int cc = wv; cc < nlive; cc += 2) {
       float *dst = a.aud + ((size_t)(ch0 + cc) * a.nframes + f) * 256;
 #pragma unroll
@@ -252,7 +266,7 @@ __global__ __launch_bounds__(128, 1) void anr_kernel(const NrArgs a) {
       a.anr[(size_t)(kAnrStW + tb + 2 * t + 1) * nch + ch] = w[t].x;
       a.anr[(size_t)(kAnrStW + tb + 2 * t) * nch + ch] = w[t].y;
     }
-    for (int r = g; r < kAnrHist; r += 4) a.anr[(size_t)(kAnrStHist + r) * nch + ch] = T[r * kAnrRow + c];
+    _Pragma("unroll 4") for (int r = g; r < kAnrHist; r += 4) a.anr[(size_t)(kAnrStHist + r) * nch + ch] = T[r * kAnrRow + c];
     if (g == 0) {
       a.anr[(size_t)kAnrStLidx * nch + ch] = lidx;
       a.anr[(size_t)kAnrStNgamma * nch + ch] = ngamma;

@@ -71,12 +71,12 @@ WORKLOADS = {
     "ssb_agc_q15": dict(batch=4096, fft=512, kw=dict(mode=0, FLoCut=200, FHiCut=3000, AGCMode=1), q15=True,
                         name="configs[1] exactly as the firmware ships: AGCMode = 1 (gwv.cpp:15) and q15 samples either side "
                              "(Process.cpp:102-111, 936): 6 B per input complex sample"),
-    "ssb_notch": dict(batch=4096, fft=512, kw=dict(mode=0, FLoCut=200, FHiCut=3000, ANR_notchOn=1), frames=8,
+    "ssb_notch": dict(batch=4096, fft=512, kw=dict(mode=0, FLoCut=200, FHiCut=3000, ANR_notchOn=1), frames=32,
                       name="configs[1] with the automatic notch on (Xanr(), Noise.cpp:322-370, Process.cpp:862-866; SURVEY 8f rank 4): "
                            "fused kernel up to the demodulator, lane-per-channel LMS kernel, interpolator kernel"),
-    "ssb_kim": dict(batch=4096, fft=512, kw=dict(mode=0, FLoCut=200, FHiCut=3000, nrOptionSelect=1), frames=8,
+    "ssb_kim": dict(batch=4096, fft=512, kw=dict(mode=0, FLoCut=200, FHiCut=3000, nrOptionSelect=1), frames=32,
                     name="configs[1] with Kim1_NR() on (Noise.cpp:108-313, Process.cpp:844-848)"),
-    "ssb_spectral": dict(batch=4096, fft=512, kw=dict(mode=0, FLoCut=200, FHiCut=3000, nrOptionSelect=2), frames=8,
+    "ssb_spectral": dict(batch=4096, fft=512, kw=dict(mode=0, FLoCut=200, FHiCut=3000, nrOptionSelect=2), frames=32,
                          name="configs[1] with SpectralNoiseReduction() on (Noise.cpp:379-655, Process.cpp:849-851)"),
     "fft4096": dict(batch=1024, fft=4096, kw=dict(mode=0, FLoCut=400, FHiCut=600), frames=32,
                     name="configs[3]: PSK31-like narrow USB filter, 4096-pt fast-conv (synthetic generalisation), "

@@ -4,7 +4,7 @@ decay step bracketed by two FMAs) against round 3's fast block, which decides fi
 double precision (-DT41RX_AGC_SPEC=0): outputs and checkpoints must be identical bit for bit over long streams of every
 AGC mode, envelope and kernel form.
 
-  tools/build_variant.sh spec0 -DT41RX_AGC_SPEC=0
+  tools/build_variant.sh spec0 -DT41RX_AGC_SPEC=0 -DT41RX_AGC_PHASED=0
   python tools/agc_decay_check.py [--streams 24] [--frames 96]         (GPU box: runs itself once per library)
 """
 import hashlib
@@ -15,7 +15,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 L = 2048
-REF = "spec0"  # the build to compare the product with (tools/build_variant.sh spec0 -DT41RX_AGC_SPEC=0: round 3's fast block only)
+REF = "spec0"  # the build to compare the product with (tools/build_variant.sh spec0 -DT41RX_AGC_SPEC=0 -DT41RX_AGC_PHASED=0: round 3's fast block only, in both chains)
 
 
 def opt(flag, default):

@@ -860,9 +860,6 @@ __device__ __forceinline__ lanemask agc_block(AgcState &t, AgcLane &dt, const Ag
 // Every float operation is one of agc_fast_block_s()'s on the same operands, or an FMA by 1 in place of a sum: bit-identical
 // (T41RX_AGC_PHASED=0 builds the form above; tools/agc_decay_check.py, the pipelined == barrier tests and
 // tools/pipe_soak.py -- 89 529 random runs, profiles/r04_pipe_soak2.json -- compare them).
-// (In the barrier form's chain -- agc_chain(), 4-wave workgroups, the pairs already multiplied in LDS -- the same block
-// measured 3-6 % SLOWER than agc_fast_block_s(): 55.5 against 53.8 us per frame at one frame per call, 47.9 against 45.0
-// at three; it stays with the form above.)
 // Timing experiments on one box (wrong results, T41RX_AGC_X), before the bookkeeping went per block, 33.6 us per frame:
 // without the back-averages 31.3, without the bookkeeping 30.2, without the bracket 32.0, without all three 29.4; after:
 // 30.2 -> 29.9 / 29.5 / 29.7 / 28.8 -- what is left of the period is the sixteen waves' own work.

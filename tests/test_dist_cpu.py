@@ -115,3 +115,13 @@ def test_bench_refuses_two_ranks_on_one_device(built):
     p, lines = _run_bench(["--gpus", "2", "--dry-run", "--workload", "ssb"], env_extra=dict(T41RX_BENCH_FORCE_LOCAL_RANK="0"))
     assert p.returncode != 0 and not lines
     assert "same device" in (p.stderr + p.stdout)
+
+
+def test_bench_launcher_three_ranks(built):
+    """an odd world size through the same path (rendezvous, shard, broadcast, max over ranks, one line)"""
+    p, lines = _run_bench(["--gpus", "3", "--dry-run", "--workload", "ssb_agc"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len(lines) == 1
+    d = lines[0]
+    assert d["n_gpus"] == 3 and d["world_size_observed"] == 3 and d["wall_max"] == 3.0
+    assert d["channels"] == [0, 4096] and sorted(d["local_ranks"]) == [0, 1, 2]

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""GPU box: the notch / LMS kernel of the product against another build of the library (t41_sdr_amd/abl/libt41rx_NAME.so,
+"""GPU box: the noise-reduction / notch kernels of the product against another build of the library (t41_sdr_amd/abl/libt41rx_NAME.so,
 e.g. an experimental nr_kernels.hip linked with the product's other objects), bit for bit: outputs and checkpoints of the
-same streams (notch, LMS + notch, LMS, notch behind AM + AGC; two calls each), one process per library.
+same streams (notch, LMS + notch, LMS, notch behind AM + AGC, Kim, spectral, spectral + notch behind AM + AGC; two calls each), one process per library.
 usage: python tools/anr_ab_check.py NAME"""
 import hashlib
 import json
@@ -18,7 +18,9 @@ import t41_sdr_amd as T
 import siggen
 out = {}
 for name, kw, nch, nfr in [("notch", dict(ANR_notchOn=1), 37, 9), ("lms+notch", dict(nrOptionSelect=3, ANR_notchOn=1), 16, 6),
-                           ("lms", dict(nrOptionSelect=3), 50, 5), ("notch-am-agc", dict(ANR_notchOn=1, mode=2, FLoCut=-3000, FHiCut=3000, AGCMode=2), 33, 8)]:
+                           ("lms", dict(nrOptionSelect=3), 50, 5), ("notch-am-agc", dict(ANR_notchOn=1, mode=2, FLoCut=-3000, FHiCut=3000, AGCMode=2), 33, 8),
+                           ("kim", dict(nrOptionSelect=1), 21, 12), ("spectral", dict(nrOptionSelect=2), 40, 40),
+                           ("spectral-am-agc-notch", dict(nrOptionSelect=2, ANR_notchOn=1, mode=2, FLoCut=-3000, FHiCut=3000, AGCMode=3), 17, 30)]:
     p = dict(mode=0, FLoCut=200, FHiCut=3000); p.update(kw)
     nco = siggen.nco_grid(nch, seed=7)
     I, Q = siggen.make_iq(nch, 2 * nfr * 2048, nco, mode=min(p["mode"], 3), seed=31)

@@ -78,6 +78,11 @@ WORKLOADS = {
                     name="configs[1] with Kim1_NR() on (Noise.cpp:108-313, Process.cpp:844-848)"),
     "ssb_spectral": dict(batch=4096, fft=512, kw=dict(mode=0, FLoCut=200, FHiCut=3000, nrOptionSelect=2), frames=32,
                          name="configs[1] with SpectralNoiseReduction() on (Noise.cpp:379-655, Process.cpp:849-851)"),
+    "ssb_1fpl": dict(batch=4096, fft=512, kw=dict(mode=0, FLoCut=200, FHiCut=3000), frames=1,
+                     name="configs[1] in the firmware's own calling shape: ONE ProcessIQData() per launch -- one 10.67 ms frame of every "
+                          "channel per call, as ShowSpectrum() calls it (Display.cpp:339) -- streaming state through HBM every call"),
+    "ssb_4fpl": dict(batch=4096, fft=512, kw=dict(mode=0, FLoCut=200, FHiCut=3000), frames=4,
+                     name="configs[1] with 4 frames (42.7 ms of signal) buffered per call"),
     "fft4096": dict(batch=1024, fft=4096, kw=dict(mode=0, FLoCut=400, FHiCut=600), frames=32,
                     name="configs[3]: PSK31-like narrow USB filter, 4096-pt fast-conv (synthetic generalisation), "
                          "1024 channels x 16384 samples per frame"),
@@ -86,7 +91,11 @@ BYTES_PER_SAMPLE = 12.0     # 2 x f32 in + 1 x f32 out per input comp
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 DEFAULT_FRAMES = 32         # consecutive frames per channel per launch (>= 100 consecutive frames per run)
 KERNEL_SOURCES = ("t41_sdr_amd/csrc/rx_kernels.hip", "t41_sdr_amd/csrc/rx_kernels.hpp", "t41_sdr_amd/csrc/rx_internal.hpp",
-                  "t41_sdr_amd/csrc/wave_fft.hpp")
+                  "t41_sdr_amd/csrc/wave_fft.hpp", "t41_sdr_amd/csrc/nr_kernels.hip", "t41_sdr_amd/csrc/nr_kernels.hpp")
+# what the default run times behind the headline (N = 1): every mode and sample format the README claims, each replayed
+# against the oracle, and the headline workload in the firmware's own calling shape (1 frame per call) and at 4 frames
+OTHER_WORKLOADS = ("nfm", "nfm_atan", "am", "sam", "fft4096", "ssb_agc", "ssb_q15", "ssb_agc_q15", "sam_agc", "ssb_time_major",
+                   "ssb_1fpl", "ssb_4fpl")
 
 
 def kernel_source_hash():
@@ -348,7 +357,7 @@ def main():
     ap.add_argument("--frames-per-launch", type=int, default=0,
                     help="consecutive frames per channel per launch (default %d; 1 = one ProcessIQData() per launch)" % DEFAULT_FRAMES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-other-workloads", action="store_true", help="skip the nfm / fft4096 / ssb_agc timings behind the headline (N = 1, ssb)")
+    ap.add_argument("--no-other-workloads", action="store_true", help="skip the other modes' timings + parity checks behind the headline (N = 1, ssb)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="ssb")
     ap.add_argument("--dry-run", action="store_true", help="CPU-only rehearsal of the multi-rank plumbing (gloo)")
     args = ap.parse_args()
@@ -436,16 +445,19 @@ def main():
     if rank == 0 and world == 1 and args.workload == "ssb" and not args.no_other_workloads:
         # BASELINE configs[2] / [3] and the firmware's default AGC mode, timed in this same run
         others = {}
-        for name in ("nfm", "fft4096", "ssb_agc", "ssb_time_major"):
+        for name in OTHER_WORKLOADS:
             w = Workload(torch, T, name, 1, 0, local_rank, dev, None, 0)
-            _, kms = w.time(12, 4)
+            # >= 384 frames of every channel in the timed region: 12 launches of 32 frames, 96 of 4, 384 of 1
+            wsteps, wwarm = max(12, 384 // w.frames), 4
+            _, kms = w.time(wsteps, wwarm)
             r = w.roofline(kms)
-            entry = {"workload": w.wl["name"], "batch": w.n, "frames_per_launch": w.frames, "kernel_ms": r["kernel_ms"],
-                     "us_per_frame": r["us_per_frame"], "frac": r["frac"], "achieved_GBs": r["achieved"], "traffic": r["traffic"]}
+            entry = {"workload": w.wl["name"], "batch": w.n, "frames_per_launch": w.frames, "steps": wsteps, "warmup": wwarm,
+                     "kernel_ms": r["kernel_ms"], "us_per_frame": r["us_per_frame"], "frac": r["frac"], "achieved_GBs": r["achieved"],
+                     "traffic": r["traffic"], "dtype": "f32" if not w.q15 else "f32 (q15 samples in and out)"}
             if not os.environ.get("T41RX_BENCH_NOCHECK"):
-                # every launch of this workload's run (4 warm-up + 12 timed), replayed and compared with the oracle; the
+                # every launch of this workload's run (warm-up + timed), replayed and compared with the oracle; the
                 # replay must reproduce the timed pass bit for bit (round 3 checked 2 of the 16 and could not assert that)
-                entry["parity_check"] = parity_check(torch, w, 16, 16, sample=8 if w.fft_length == 4096 else 16)
+                entry["parity_check"] = parity_check(torch, w, wwarm + wsteps, wwarm + wsteps, sample=8 if w.fft_length == 4096 else 16)
             others[name] = entry
             w.free()
         line["other_workloads"] = others

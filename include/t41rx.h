@@ -37,6 +37,16 @@ extern "C" {
 
 #define T41RX_ABI_VERSION 5
 
+/* The library is built with -fvisibility=hidden and an export list (t41_sdr_amd/csrc/exports.map): the entry points
+ * declared here and in t41tx.h are its only dynamic symbols. */
+#ifndef T41RX_API
+#if defined(__GNUC__) || defined(__clang__)
+#define T41RX_API __attribute__((visibility("default")))
+#else
+#define T41RX_API
+#endif
+#endif
+
 /* status codes */
 #define T41RX_OK 0
 #define T41RX_ERR_ARG (-1)        /* bad argument (null pointer, size, range) */
@@ -95,14 +105,14 @@ typedef struct t41rx_params {
 typedef struct t41rx_ctx t41rx_ctx; /* opaque: coefficient arrays + per-channel state + device buffers */
 
 /* ---- library ---- */
-int         t41rx_abi_version(void);
-const char *t41rx_strerror(int status);
-const char *t41rx_last_error(void);          /* thread-local detail of the last failing call */
-int         t41rx_supported_fft_length(int fft_length); /* 1 for 512, 1024, 2048, 4096 */
+T41RX_API int         t41rx_abi_version(void);
+T41RX_API const char *t41rx_strerror(int status);
+T41RX_API const char *t41rx_last_error(void);          /* thread-local detail of the last failing call */
+T41RX_API int         t41rx_supported_fft_length(int fft_length); /* 1 for 512, 1024, 2048, 4096 */
 
 /* Defaults of gwv.cpp:14-96 / bands[] T41_SDR.ino:145-168 (20 m row: USB, 200..3000 Hz) with
  * AGCMode forced to 0. */
-void t41rx_default_params(t41rx_params *p);
+T41RX_API void t41rx_default_params(t41rx_params *p);
 
 /* ---- coefficient design: host-side, no GPU needed ----
  * The arrays CalcFilters() (Filter.cpp:235-249), InitFilterMask() (Filter.cpp:260-284),
@@ -115,38 +125,38 @@ void t41rx_default_params(t41rx_params *p);
  *   AGCLoadValues() leave behind, DSP_Fn.cpp:368-468; zeros for AGCMode 0) |
  *   FIR_filter_mask[2*fft_length]                                                (all f32)
  * This blob is what rank 0 broadcasts over RCCL after a filter change. */
-size_t t41rx_coeff_blob_bytes(int fft_length);
-int    t41rx_design_coeffs(const t41rx_params *p, void *blob, size_t blob_bytes);
+T41RX_API size_t t41rx_coeff_blob_bytes(int fft_length);
+T41RX_API int    t41rx_design_coeffs(const t41rx_params *p, void *blob, size_t blob_bytes);
 
 /* ---- context ---- */
 /* InitializeDataArrays() (T41_SDR.ino:473-667): allocate state for n_channels channels on HIP
  * device `device_id`, power-on state, design + upload coefficients for *p. */
-int t41rx_create(t41rx_ctx **out, int device_id, int n_channels, const t41rx_params *p);
-int t41rx_destroy(t41rx_ctx *ctx);
+T41RX_API int t41rx_create(t41rx_ctx **out, int device_id, int n_channels, const t41rx_params *p);
+T41RX_API int t41rx_destroy(t41rx_ctx *ctx);
 
 /* SetupMode()/CalcFilters() (Filter.cpp:235-249, 341-385): parameters changed between two
  * ProcessIQData() calls.  Coefficients are re-designed and uploaded; like the reference, the
  * streaming state (FIR delay lines etc.) is NOT reset.  fft_length cannot change. */
-int t41rx_set_params(t41rx_ctx *ctx, const t41rx_params *p);
-int t41rx_get_params(const t41rx_ctx *ctx, t41rx_params *p);
+T41RX_API int t41rx_set_params(t41rx_ctx *ctx, const t41rx_params *p);
+T41RX_API int t41rx_get_params(const t41rx_ctx *ctx, t41rx_params *p);
 
 /* Coefficient blob of the context (see t41rx_design_coeffs).  set = install a blob designed
  * elsewhere (e.g. received by broadcast); it must match the context's fft_length.  The context
  * takes over the parameters stored in the blob (mode, AGCMode, cut-offs, gains ...), so afterwards
  * t41rx_get_params() returns the designer's and a later t41rx_set_params() starts from them. */
-int t41rx_get_coeffs(const t41rx_ctx *ctx, void *blob, size_t blob_bytes);
-int t41rx_set_coeffs(t41rx_ctx *ctx, const void *blob, size_t blob_bytes);
+T41RX_API int t41rx_get_coeffs(const t41rx_ctx *ctx, void *blob, size_t blob_bytes);
+T41RX_API int t41rx_set_coeffs(t41rx_ctx *ctx, const void *blob, size_t blob_bytes);
 
 /* NCOFreq (T41_SDR.ino:131, Tune.cpp:141-196), one value per channel, host array of n_channels.
  * Phase-continuous: the oscillator state (Osc_Vect_Q/I, Freq_Shift.cpp:13-14) is kept. */
-int t41rx_set_nco_freq(t41rx_ctx *ctx, const int32_t *nco_freq_hz, int n);
+T41RX_API int t41rx_set_nco_freq(t41rx_ctx *ctx, const int32_t *nco_freq_hz, int n);
 
 /* Power-on state: Osc_Vect_Q = 1, Osc_Vect_I = 0, all delay lines zero, first_block = 1
  * (Freq_Shift.cpp:13-14, Process.cpp:42,47). */
-int t41rx_reset(t41rx_ctx *ctx);
+T41RX_API int t41rx_reset(t41rx_ctx *ctx);
 
-int t41rx_n_channels(const t41rx_ctx *ctx);
-int t41rx_frame_len(const t41rx_ctx *ctx);
+T41RX_API int t41rx_n_channels(const t41rx_ctx *ctx);
+T41RX_API int t41rx_frame_len(const t41rx_ctx *ctx);
 
 /* How the frames of one process call lie in I / Q / audio (f32 and q15 entry points alike).  The reference has one
  * channel and one frame per call (float_buffer_L/R[2048], T41_SDR.ino:375-376), so a batch of channels over several
@@ -161,19 +171,19 @@ int t41rx_frame_len(const t41rx_ctx *ctx);
  * time-major layout (T41RX_ERR_UNSUPPORTED otherwise; a later set_params to a long fft_length is refused likewise). */
 #define T41RX_LAYOUT_CHANNEL_MAJOR 0
 #define T41RX_LAYOUT_TIME_MAJOR 1
-int t41rx_set_buffer_layout(t41rx_ctx *ctx, int layout);
-int t41rx_get_buffer_layout(const t41rx_ctx *ctx);
+T41RX_API int t41rx_set_buffer_layout(t41rx_ctx *ctx, int layout);
+T41RX_API int t41rx_get_buffer_layout(const t41rx_ctx *ctx);
 
 /* ---- the hot path: ProcessIQData() on every channel ----
  * Device-pointer form: dI, dQ, dAudio are device pointers ([n_channels][n_frames*frame_len], or time-major:
  * t41rx_set_buffer_layout);
  * the kernel is enqueued on `hip_stream` (a hipStream_t, may be NULL = default stream) and the
  * call returns without synchronising. */
-int t41rx_process_device(t41rx_ctx *ctx, const float *dI, const float *dQ, float *dAudio,
+T41RX_API int t41rx_process_device(t41rx_ctx *ctx, const float *dI, const float *dQ, float *dAudio,
                          int n_frames, void *hip_stream);
 /* Host-pointer form (the reference's calling convention: caller-owned host arrays): copies
  * in, runs the same kernel, copies out, synchronises. */
-int t41rx_process_host(t41rx_ctx *ctx, const float *I, const float *Q, float *audio,
+T41RX_API int t41rx_process_host(t41rx_ctx *ctx, const float *I, const float *Q, float *audio,
                        int n_frames);
 
 /* The same call on the firmware's own sample format either side of the path: q15 samples as the
@@ -186,24 +196,39 @@ int t41rx_process_host(t41rx_ctx *ctx, const float *I, const float *Q, float *au
  * t41rx_set_buffer_layout).  The side outputs and stage taps work here as on the f32 entry points (ABI 5): the
  * reference computes its display FFT and audio spectrum inside every ProcessIQData() call on exactly these q15-fed
  * buffers (Process.cpp:107-108 -> :184-186, :211-215, :550-570). */
-int t41rx_process_device_q15(t41rx_ctx *ctx, const int16_t *dQ_in_L, const int16_t *dQ_in_R,
+T41RX_API int t41rx_process_device_q15(t41rx_ctx *ctx, const int16_t *dQ_in_L, const int16_t *dQ_in_R,
                              int16_t *dQ_out_L, int n_frames, void *hip_stream);
-int t41rx_process_host_q15(t41rx_ctx *ctx, const int16_t *Q_in_L, const int16_t *Q_in_R,
+T41RX_API int t41rx_process_host_q15(t41rx_ctx *ctx, const int16_t *Q_in_L, const int16_t *Q_in_R,
                            int16_t *Q_out_L, int n_frames);
 
 /* ---- checkpoint of the streaming state (the reference never persists it) ----
- * The buffer starts with a 32-byte header (magic, abi, fft_length, n_channels, floats per channel,
- * 3 reserved); t41rx_set_state() refuses (T41RX_ERR_STATE) a checkpoint of another ABI, FFT length
- * or channel count, and one whose AGC state words, oscillator amplitude or synchronous-detector PLL
- * words (phase in [0, 2 pi], frequency within +-pll_fmax) are out of range.  The checkpoint is the
- * path's streaming state; the memories of the optional side stages -- the display FFT's zoom filters
- * and ring, the noise-reduction / notch state -- are not in it.
- * t41rx_get_state() also returns T41RX_ERR_STATE if a wait inside the pipelined AGC / SAM kernels has run out since
- * the last t41rx_reset() (their waits are bounded so that a broken hand-over cannot hang the GPU; it cannot happen
- * unless the kernel is wrong, and then the samples are not to be trusted). */
-size_t t41rx_state_bytes(const t41rx_ctx *ctx);
-int    t41rx_get_state(t41rx_ctx *ctx, void *host_buf, size_t bytes);
-int    t41rx_set_state(t41rx_ctx *ctx, const void *host_buf, size_t bytes);
+ * Layout (ABI 5): a 32-byte header of eight int32 words
+ *     [0] magic "T41S"  [1] T41RX_ABI_VERSION  [2] fft_length  [3] n_channels  [4] floats per channel record
+ *     [5] section mask (below)  [6] spectrumZoom of the display section (0 without one)  [7] reserved, 0
+ * then the path's per-channel records (FIR delay lines, oscillator, overlap block, AGC, demodulator words), then the
+ * sections header word 5 names, in this order:
+ *     bit 0  noise reduction / notch: Xanr()'s taps, delay line and leak words, then the Kim / spectral per-bin memories
+ *            (Noise.cpp:19-56) -- present once one of those stages has run in this context;
+ *     bit 1  display FFT: zoom filters, ring, FFT_spec_old (FFT.cpp:14-26) -- present while
+ *            t41rx_set_display_spectrum() is on.
+ * t41rx_state_bytes() therefore GROWS when a noise-reduction stage first runs or the display spectrum is switched on:
+ * query it right before every t41rx_get_state() (a buffer sized at creation gets T41RX_ERR_STATE "state buffer too
+ * small").  fft_length cannot change on a live context, so the path records' size never does.
+ * t41rx_set_state() refuses (T41RX_ERR_STATE) a checkpoint of another ABI, FFT length or channel count, one with an
+ * unknown section bit or a size that does not follow from its header, a display section while the display spectrum is
+ * off here or taken at another spectrumZoom, and any word the kernels use as an index, a divisor or a state number that
+ * is out of range or not integral: AGC state words, oscillator amplitude, synchronous-detector PLL words (phase in
+ * [0, 2 pi], frequency within +-pll_fmax), the notch's leak index, the noise reduction's ring pointers, the zoom ring's
+ * pointer.  What it does to the side stages: a section the checkpoint carries is restored; a memory this context has
+ * allocated but the checkpoint does not carry goes back to its power-on values (InitializeDataArrays() /
+ * SpectralNoiseReductionInit() / ZoomFFTPrep()) -- never the values of the stream being replaced.
+ * T41RX_ERR_STATE is also what t41rx_get_state(), t41rx_process_host() and t41rx_process_host_q15() -- the calls that
+ * synchronise -- return if a wait inside the pipelined AGC / SAM kernels has run out since the last t41rx_reset() or
+ * restored checkpoint (their waits are bounded so that a broken hand-over cannot hang the GPU; it cannot happen unless
+ * the kernel is wrong, and then the samples are not to be trusted). */
+T41RX_API size_t t41rx_state_bytes(const t41rx_ctx *ctx);
+T41RX_API int    t41rx_get_state(t41rx_ctx *ctx, void *host_buf, size_t bytes);
+T41RX_API int    t41rx_set_state(t41rx_ctx *ctx, const void *host_buf, size_t bytes);
 
 /* ---- stage taps for parity debugging (device pointers, may each be NULL) ----
  * When set, the next process calls also write, per channel and frame:
@@ -212,7 +237,7 @@ int    t41rx_set_state(t41rx_ctx *ctx, const void *host_buf, size_t bytes);
  *   demod    : [n_channels][n_frames*fft_length/2] audio @24 kS/s before interpolation
  * max_frames = the n_frames the buffers are sized for: a process call with more frames is refused
  * (T41RX_ERR_ARG) instead of writing past them.  fft_length 512 only (T41RX_ERR_UNSUPPORTED). */
-int t41rx_set_debug_taps(t41rx_ctx *ctx, float *d_post_nco, float *d_dec, float *d_demod, int max_frames);
+T41RX_API int t41rx_set_debug_taps(t41rx_ctx *ctx, float *d_post_nco, float *d_dec, float *d_demod, int max_frames);
 
 /* ---- the path's display by-product: the audio spectrum and the S-meter's input ----
  * What ProcessIQData() leaves behind when updateDisplayFlag == 1 (Process.cpp:550-570; NFM:
@@ -224,7 +249,7 @@ int t41rx_set_debug_taps(t41rx_ctx *ctx, float *d_post_nco, float *d_dec, float 
  *   d_max   : [n_channels][n_frames][3]     audioMaxSquared, (float)AudioMaxIndex, audioMaxSquaredAve
  * and updates the per-channel audioMaxSquaredAve.  The pixel mapping (audioYPixel) is display
  * code and stays with the caller.  fft_length 512; f32 and q15 entry points.  max_frames as above. */
-int t41rx_set_audio_spectrum(t41rx_ctx *ctx, float *d_spect, float *d_max, int max_frames);
+T41RX_API int t41rx_set_audio_spectrum(t41rx_ctx *ctx, float *d_spect, float *d_max, int max_frames);
 
 /* ---- the display FFT: what ShowSpectrum() draws from (FFT.cpp:67-251) ----
  * CalcZoom1Magn() (spectrumZoom = 0: Hann-windowed 512-point FFT of the frame's first 512 I/Q samples
@@ -239,7 +264,7 @@ int t41rx_set_audio_spectrum(t41rx_ctx *ctx, float *d_spect, float *d_max, int m
  *   d_spec_old : [n_channels][n_frames][512]  FFT_spec_old
  * Setting it (or changing spectrumZoom) starts from cleared zoom filters, ring and low-pass memory.
  * fft_length 512; f32 and q15 entry points; max_frames as for the stage taps. */
-int t41rx_set_display_spectrum(t41rx_ctx *ctx, float *d_spec, float *d_spec_old, int spectrumZoom, int max_frames);
+T41RX_API int t41rx_set_display_spectrum(t41rx_ctx *ctx, float *d_spec, float *d_spec_old, int spectrumZoom, int max_frames);
 
 #ifdef __cplusplus
 }

@@ -16,6 +16,14 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#ifndef T41RX_API /* exported entry point (see t41rx.h) */
+#if defined(__GNUC__) || defined(__clang__)
+#define T41RX_API __attribute__((visibility("default")))
+#else
+#define T41RX_API
+#endif
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -30,22 +38,22 @@ typedef struct t41tx_params {
 
 typedef struct t41tx_ctx t41tx_ctx;
 
-void t41tx_default_params(t41tx_params *p);             /* USB, 1, 0 (gwv.cpp:73-74) */
+T41RX_API void t41tx_default_params(t41tx_params *p);             /* USB, 1, 0 (gwv.cpp:73-74) */
 /* SetupMode() for transmit: allocate n_channels exciters on HIP device device_id, filter states cleared */
-int t41tx_create(t41tx_ctx **out, int device_id, int n_channels, const t41tx_params *p);
-int t41tx_destroy(t41tx_ctx *ctx);
-int t41tx_set_params(t41tx_ctx *ctx, const t41tx_params *p);  /* states are kept, like the firmware's */
-int t41tx_reset(t41tx_ctx *ctx);                               /* all CMSIS instance states to zero */
-int t41tx_n_channels(const t41tx_ctx *ctx);
+T41RX_API int t41tx_create(t41tx_ctx **out, int device_id, int n_channels, const t41tx_params *p);
+T41RX_API int t41tx_destroy(t41tx_ctx *ctx);
+T41RX_API int t41tx_set_params(t41tx_ctx *ctx, const t41tx_params *p);  /* states are kept, like the firmware's */
+T41RX_API int t41tx_reset(t41tx_ctx *ctx);                               /* all CMSIS instance states to zero */
+T41RX_API int t41tx_n_channels(const t41tx_ctx *ctx);
 
 /* ExciterIQData() on every channel, n_frames consecutive frames of 2048 samples per queue.
  * Device pointers, [n_channels][n_frames * 2048] int16 each; dQ_in_R_Ex may be NULL: the firmware
  * decimates that queue and then overwrites the result with a copy of the L channel
  * (Exciter.cpp:98), so its samples never reach the output.  Enqueued on hip_stream, no sync. */
-int t41tx_process_device_q15(t41tx_ctx *ctx, const int16_t *dQ_in_L_Ex, const int16_t *dQ_in_R_Ex,
+T41RX_API int t41tx_process_device_q15(t41tx_ctx *ctx, const int16_t *dQ_in_L_Ex, const int16_t *dQ_in_R_Ex,
                              int16_t *dQ_out_L_Ex, int16_t *dQ_out_R_Ex, int n_frames, void *hip_stream);
 /* host-pointer form: copies in, runs the same kernel, copies out, synchronises */
-int t41tx_process_host_q15(t41tx_ctx *ctx, const int16_t *Q_in_L_Ex, const int16_t *Q_in_R_Ex,
+T41RX_API int t41tx_process_host_q15(t41tx_ctx *ctx, const int16_t *Q_in_L_Ex, const int16_t *Q_in_R_Ex,
                            int16_t *Q_out_L_Ex, int16_t *Q_out_R_Ex, int n_frames);
 
 #ifdef __cplusplus

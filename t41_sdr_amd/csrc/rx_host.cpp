@@ -867,9 +867,11 @@ int t41rx_set_state(t41rx_ctx *ctx, const void *host_buf, size_t bytes) {
       const float lidx = anr[(size_t)kAnrStLidx * ctx->nchan + c], ng = anr[(size_t)kAnrStNgamma * ctx->nchan + c];
       if (!(lidx >= 0.0f && lidx <= 1000.0f) || !std::isfinite(ng)) return fail(T41RX_ERR_STATE, "checkpoint: notch leak words out of range");
       const float *sc = spec + (size_t)kNrSpecFloats * (size_t)c + kNrScal;
+      // (the kernel casts them with (int) and uses them as array indices and counters: integral values only)
+      auto whole = [](float v) { return v == std::floor(v); };
       if (!(sc[0] >= 0.0f && sc[0] <= 2.0f) || !(sc[1] >= 0.0f && sc[1] <= 14.0f) || !(sc[2] == 0.0f || sc[2] == 1.0f || sc[2] == 2.0f) ||
-          !(sc[3] >= 0.0f && sc[3] <= 1.0e6f))
-        return fail(T41RX_ERR_STATE, "checkpoint: noise-reduction ring pointers out of range");
+          !(sc[3] >= 0.0f && sc[3] <= 1.0e6f) || !whole(sc[0]) || !whole(sc[1]) || !whole(sc[3]))
+        return fail(T41RX_ERR_STATE, "checkpoint: noise-reduction ring pointers out of range or not integral");
     }
   }
   if (sec & kSecDisp) {

@@ -922,8 +922,11 @@ __device__ __forceinline__ lanemask agc_block_phased(AgcState &st, AgcLane &d, c
     if (__builtin_expect((any | d.in0) == 0, 1)) {
       // no attack, no lane in state 0: every lane stays in its decay state unless its fast decay has reached save_volts --
       // volts does not rise without an attack (diff < 0, multipliers >= 0, monotonic roundings), so "volts > thr" before
-      // the last step implies it before the three others
-      ok &= lanes_gt(vin[3], d.thr);
+      // the last step implies it before the three others -- EXCEPT through the clamp of :629: a block that starts below
+      // min_volts (a live set_params / set_coeffs raised it, or a restored checkpoint) is lifted to it at step 0, so
+      // vin[0] may sit at or below the threshold while vin[1..3] = min_volts sit above it; once clamped the three are
+      // equal, so the first and the last comparison cover every step
+      ok &= lanes_gt(vin[0], d.thr) & lanes_gt(vin[3], d.thr);
     } else {
       lanemask in0 = d.in0, pend = d.pend;
       float save_volts = st.save_volts;
@@ -1835,17 +1838,22 @@ static_assert(!Geo<0>::kResident || (Geo<0>::kH1 + 24 <= Geo<0>::kSlice && Geo<0
 #ifdef T41RX_CLK
 // Diagnostic build only (-DT41RX_CLK, tools/clock_probe.py): every wave leaves the shader-clock and the constant
 // 100 MHz counter's ticks between its start and its end here (its clock under this load = their ratio x 100 MHz).
-__device__ unsigned long long g_t41_clk[2 * 8192];
+__device__ __attribute__((visibility("default"))) unsigned long long g_t41_clk[4 * 8192];  // per wave: shader cycles, 100 MHz ticks, start tick, HW_ID | XCC_ID << 32
 #define T41RX_CLK_BEGIN()                                                                                              \
   unsigned long long clk_c0, clk_r0;                                                                                   \
   asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk_c0), "=s"(clk_r0)::"memory")
 #define T41RX_CLK_END(wave_id)                                                                                         \
   do {                                                                                                                 \
     unsigned long long c1_, r1_;                                                                                       \
+    unsigned hw_, xcc_;                                                                                                \
     asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c1_), "=s"(r1_)::"memory"); \
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));                                                  \
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));                                                \
     if ((threadIdx.x & 63) == 0 && (wave_id) < 8192) {                                                                 \
-      g_t41_clk[2 * (wave_id)] = c1_ - clk_c0;                                                                         \
-      g_t41_clk[2 * (wave_id) + 1] = r1_ - clk_r0;                                                                     \
+      g_t41_clk[4 * (wave_id)] = c1_ - clk_c0;                                                                         \
+      g_t41_clk[4 * (wave_id) + 1] = r1_ - clk_r0;                                                                     \
+      g_t41_clk[4 * (wave_id) + 2] = clk_r0;                                                                           \
+      g_t41_clk[4 * (wave_id) + 3] = hw_ | ((unsigned long long)(xcc_ & 0xf) << 32);                                   \
     }                                                                                                                  \
   } while (0)
 #else
@@ -3418,7 +3426,7 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
   T41RX_CLK_END(job);
 }
 #ifdef T41RX_CLK
-extern "C" int t41rx_debug_read_clk(unsigned long long *host, int n) {
+extern "C" __attribute__((visibility("default"))) int t41rx_debug_read_clk(unsigned long long *host, int n) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_t41_clk), sizeof(unsigned long long) * (size_t)n);
 }
 #endif

@@ -46,6 +46,11 @@ CASES = [
     ("am-agc-pipe", dict(mode=2, FLoCut=-4000, FHiCut=4000, AGCMode=3), 5),
     ("sam-pipe", dict(mode=8, FLoCut=-4000, FHiCut=4000), 6),
     ("notch", dict(mode=0, FLoCut=200, FHiCut=3000, ANR_notchOn=1), 3),
+    # the kernel forms that compute their I / Q / out addresses from chan_stride / frame_stride and were not compared
+    ("sam-agc-pipe", dict(mode=8, FLoCut=-4000, FHiCut=4000, AGCMode=1), 7),  # SAM behind the AGC: the PSA pipeline (kSkew 4)
+    ("kim", dict(mode=0, FLoCut=200, FHiCut=3000, nrOptionSelect=1), 5),         # launch_back512 behind the stage kernels
+    ("spectral", dict(mode=0, FLoCut=200, FHiCut=3000, nrOptionSelect=2), 12),   # (its first 19 half-blocks pass the audio through)
+    ("spectral-agc", dict(mode=0, FLoCut=200, FHiCut=3000, nrOptionSelect=2, AGCMode=2), 12),
 ]
 
 
@@ -95,6 +100,44 @@ def test_time_major_q15_and_host_entry_points(T):
     oc = c.ProcessIQData(I, Q)
     od = d.ProcessIQData(np.ascontiguousarray(I.reshape(nch, nfr, L).transpose(1, 0, 2)), np.ascontiguousarray(Q.reshape(nch, nfr, L).transpose(1, 0, 2)))
     assert np.array_equal(oc.reshape(nch, nfr, L).transpose(1, 0, 2), od)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt", ["f32", "q15"])
+def test_time_major_side_outputs_and_taps(T, fmt):
+    """the <DEBUG, WQ15> instantiations and the side-output kernels under the time-major layout -- the audio
+    spectrum / S-meter words, the display FFT and the stage taps keep their [n_channels][n_frames][...] shapes whatever
+    the call buffers' layout, and hold the same bits"""
+    import torch
+    kw = dict(mode=0, FLoCut=200, FHiCut=3000, AGCMode=1)
+    nch, nfr = 21, 5
+    nco = siggen.nco_grid(nch, seed=6)
+    I, Q = siggen.make_iq(nch, nfr * L, nco, mode=0, seed=24)
+    if fmt == "q15":
+        I = np.clip(np.round(I * 32768.0), -32768, 32767).astype(np.int16)
+        Q = np.clip(np.round(Q * 32768.0), -32768, 32767).astype(np.int16)
+    outs = {}
+    for layout in ("channel", "time"):
+        rx = T.RxChain(nch, T.default_params(**kw), NCOFreq=nco)
+        rx.set_buffer_layout(layout)
+        spect, mx = torch.zeros(nch, nfr, 1024, device="cuda"), torch.zeros(nch, nfr, 3, device="cuda")
+        spec, old = torch.zeros(nch, nfr, 512, device="cuda"), torch.zeros(nch, nfr, 512, device="cuda")
+        dec, dem = torch.zeros(nch, nfr * 512, device="cuda"), torch.zeros(nch, nfr * 256, device="cuda")
+        rx.set_audio_spectrum(spect, mx)
+        rx.set_display_spectrum(spec, old, spectrumZoom=2)
+        rx.set_debug_taps(dec=dec, demod=dem)
+        dI, dQ = torch.from_numpy(I).cuda(), torch.from_numpy(Q).cuda()
+        if layout == "time":
+            dI = dI.view(nch, nfr, L).transpose(0, 1).contiguous()
+            dQ = dQ.view(nch, nfr, L).transpose(0, 1).contiguous()
+        o = rx.ProcessIQData_q15(dQ, dI) if fmt == "q15" else rx.ProcessIQData(dI, dQ)
+        if layout == "time":
+            o = o.transpose(0, 1).reshape(nch, nfr * L)
+        torch.cuda.synchronize()
+        outs[layout] = [t.cpu().numpy() for t in (o, spect, mx, spec, old, dec, dem)] + [rx.get_state()]
+    for a, b in zip(outs["channel"], outs["time"]):
+        assert np.array_equal(a, b)
+    assert np.abs(outs["time"][1]).max() > 0 and np.abs(outs["time"][3]).max() > 0 and np.abs(outs["time"][6]).max() > 0
 
 
 @pytest.mark.gpu

@@ -33,6 +33,34 @@ def test_every_declared_symbol_is_exported(T):
     assert lib.t41rx_abi_version() == 5
 
 
+def _declared(header):
+    hdr = open(os.path.join(ROOT, "include", header)).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return set(re.findall(r"\b(t41[rt]x_[a-z0-9_]+)\s*\(", hdr))
+
+
+def test_nothing_but_the_declared_symbols_is_exported(T):
+    """the converse: libt41rx.so is built with -fvisibility=hidden and an export list
+    (t41_sdr_amd/csrc/exports.map); its dynamic symbol table is the two headers' entry points and nothing else --
+    no t41:: C++ symbol, no kernel stub, no host helper, no diagnostic hook"""
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", "--defined-only", T.LIB_PATH], text=True)
+    exported = {line.split()[-1].split("@")[0] for line in out.splitlines() if line.strip()}
+    declared = _declared("t41rx.h") | _declared("t41tx.h")
+    assert exported == declared, "exported but not declared: %s; declared but not exported: %s" % (
+        sorted(exported - declared), sorted(declared - exported))
+    # and the export list itself names exactly those (plus the diagnostic builds' t41rx_debug_* pattern)
+    m = open(os.path.join(ROOT, "t41_sdr_amd", "csrc", "exports.map")).read()
+    m = re.sub(r"#.*", "", m)
+    listed = set(re.findall(r"\b(t41[rt]x_[a-z0-9_]+);", m))
+    assert listed == declared
+    # every declaration carries the export attribute (a declaration without it would be hidden by -fvisibility=hidden)
+    for header in ("t41rx.h", "t41tx.h"):
+        hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", header)).read(), flags=re.S)
+        for name in _declared(header):
+            assert re.search(r"T41RX_API[^;]*\b%s\s*\(" % name, hdr), "%s lacks T41RX_API in %s" % (name, header)
+
+
 def test_params_struct_layout_matches_header(T):
     hdr = open(os.path.join(ROOT, "include", "t41rx.h")).read()
     body = re.search(r"typedef struct t41rx_params \{(.*?)\} t41rx_params;", hdr, re.S).group(1)

@@ -281,6 +281,63 @@ def test_gpu_stage_in_isolation(built, name):
         assert e.max() <= tol and (e < 1e-5).mean() > 0.97 and np.median(e) < 5e-6, ((e < 1e-5).mean(), np.median(e), e.max())
 
 
+def _exact_stage_and_interpolators(pre, kw):
+    """the stage as the float64 model evaluates it (tests/nr_model.py) and exact interpolators (Process.cpp:917-931:
+    upfirdn with the reversed CMSIS tap arrays, as tests/f64_model.py), per channel"""
+    from scipy import signal
+    p = O.default_params(**kw)
+    c = O.design(p)
+    ca = O.coeff_arrays(c, 512)
+    g1, g2 = ca["int1"].astype(np.float64)[::-1], ca["int2"].astype(np.float64)[::-1]
+    out = np.empty((pre.shape[0], 8 * pre.shape[1]))
+    for ch in range(pre.shape[0]):
+        aud = M.run(pre[ch], p.FLoCut, p.FHiCut, nrOptionSelect=p.nrOptionSelect, ANR_notchOn=p.ANR_notchOn,
+                    alpha=float(p.NR_alpha), beta=float(p.NR_beta), psi=float(p.NR_PSI))
+        a1 = signal.upfirdn(g1, aud, up=2)[:2 * aud.size]
+        out[ch] = signal.upfirdn(g2, a1, up=4)[:4 * a1.size] * float(_vol_scale(p.audioVolume))
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["kim", "spectral"])
+def test_gpu_stage_is_as_close_to_the_exact_model_as_the_oracle(built, name):
+    """The evidence behind the 2e-5 / 1e-4 isolation bars.  Kim's gain 1 - M / E cancels where the
+    noise is stationary and the spectral function divides by small noise estimates: an f32 evaluation -- the
+    reference's, the oracle's, the kernel's, each with its own FFT and summation order -- sits a few 1e-5 away from the
+    functions evaluated exactly (tests/test_noise_reduction.py::test_kim_matches_the_f64_model allows the ORACLE 5e-5).
+    On identical input (the HIP path's own pre-stage audio): the HIP output is no farther from the float64 model than
+    the oracle is, frame by frame in distribution; the per-frame distributions go into the assertion message."""
+    import torch
+    import t41_sdr_amd as T
+    kw, tol, how = NR_CASES[name]
+    nch, nfr = 24, 40
+    nco = siggen.nco_grid(nch, seed=15)
+    I, Q = siggen.make_iq(nch, nfr * L, nco, mode=0, seed=150)
+    rx = T.RxChain(nch, T.default_params(**kw), NCOFreq=nco)
+    tap = torch.zeros(nch, nfr * D, device="cuda")
+    rx.set_debug_taps(demod=tap)
+    got = rx.ProcessIQData(torch.from_numpy(I).cuda(), torch.from_numpy(Q).cuda()).cpu().numpy()
+    pre = tap.cpu().numpy()
+    orc = _oracle_stage_and_interpolators(pre, kw)
+    exact = _exact_stage_and_interpolators(pre, kw)
+    d_hip = siggen.block_rel_err(got, exact, L)
+    d_orc = siggen.block_rel_err(orc, exact, L)
+    d_go = siggen.block_rel_err(got, orc, L)
+    # the spectral function's integer decisions (smoothing width, speech-presence threshold) may come out differently in
+    # f64 in single frames: compared where the ORACLE agrees with the model to 1e-3 (test_spectral_matches_the_f64_model)
+    ok = d_orc < 1e-3
+    assert ok.mean() > 0.97
+
+    def dist(d):
+        return "median %.1e p90 %.1e p99 %.1e max %.1e" % (np.median(d), np.percentile(d, 90), np.percentile(d, 99), d.max())
+    msg = "%s per frame -- HIP vs exact: %s | oracle vs exact: %s | HIP vs oracle: %s (<= 1e-5 on %.1f %% of frames)" % (
+        name, dist(d_hip[ok]), dist(d_orc[ok]), dist(d_go), 100.0 * (d_go <= 1e-5).mean())
+    print(msg)
+    for q in (50, 90, 99, 100):  # no farther from the exact evaluation than the oracle, all along the distribution
+        assert np.percentile(d_hip[ok], q) <= 1.5 * np.percentile(d_orc[ok], q) + 2e-6, msg
+    assert d_go.max() <= tol, msg
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["notch-late", "lms", "kim", "spectral"])
 def test_gpu_whole_path_with_nr(built, name):

@@ -50,9 +50,32 @@ def main():
     torch.cuda.synchronize()
     lib = _lib.load()
     nw = nch if fft == 512 else 4 * nch  # waves that report (the fused long-FFT kernel runs four per channel)
-    buf = (C.c_ulonglong * (2 * nw))()
-    rc = lib.t41rx_debug_read_clk(buf, 2 * nw)
-    a = np.frombuffer(buf, dtype=np.uint64).astype(np.float64).reshape(nw, 2)
+    buf = (C.c_ulonglong * (4 * nw))()
+    rc = lib.t41rx_debug_read_clk(buf, 4 * nw)
+    raw = np.frombuffer(buf, dtype=np.uint64).reshape(nw, 4)
+    a = raw[:, :2].astype(np.float64)
+    if "--dump" in sys.argv:
+        np.save(opt("--dump", "gpurun_out/clk_dump.npy"), raw)
+        # where the launch's last tenth goes: wave lifetimes / end times (100 MHz ticks -> us) by XCD, CU, SIMD, wave slot
+        life = raw[:, 1].astype(np.float64) / 100.0
+        start = (raw[:, 2] - raw[:, 2].min()).astype(np.float64) / 100.0
+        end = start + life
+        hw = raw[:, 3]
+        xcc = ((hw >> np.uint64(32)) & np.uint64(0xf)).astype(int)
+        simd = ((hw >> np.uint64(4)) & np.uint64(3)).astype(int)
+        cu = (((hw >> np.uint64(8)) & np.uint64(0xff)).astype(int)) + 256 * xcc   # CU_ID, SH_ID, SE_ID within the XCD
+        slot = np.arange(nw) % 16
+        def by(key):
+            return {int(k): [round(float(life[key == k].mean()), 1), round(float(end[key == k].max()), 1)] for k in np.unique(key)}
+        cu_end = np.array([end[cu == k].max() for k in np.unique(cu)])
+        cu_first = np.array([end[cu == k].min() for k in np.unique(cu)])
+        print(json.dumps({"launch_span_us": round(float(end.max()), 1), "start_spread_us": round(float(start.max()), 2),
+                          "life_us_pct_0_10_50_90_100": [round(float(np.percentile(life, q)), 1) for q in (0, 10, 50, 90, 100)],
+                          "end_us_pct_0_10_50_90_100": [round(float(np.percentile(end, q)), 1) for q in (0, 10, 50, 90, 100)],
+                          "n_cus_seen": int(len(cu_end)),
+                          "cu_last_end_pct_0_50_100": [round(float(np.percentile(cu_end, q)), 1) for q in (0, 50, 100)],
+                          "cu_first_end_pct_0_50_100": [round(float(np.percentile(cu_first, q)), 1) for q in (0, 50, 100)],
+                          "by_xcc_[mean_life,last_end]": by(xcc), "by_simd": by(simd), "by_wave_slot": by(slot)}), flush=True)
     ghz = a[:, 0] / a[:, 1] * 0.1
     print(json.dumps({"args": " ".join(sys.argv[1:]), "rc": rc, "us_per_frame": round(e0.elapsed_time(e1) / reps * 1e3 / frames, 3),
                       "clock_GHz_median": round(float(np.median(ghz)), 3), "min": round(float(ghz.min()), 3), "max": round(float(ghz.max()), 3),

@@ -8,6 +8,11 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("T41RX_LIB", os.path.join(_HERE, "libt41rx.so"))  # override: kernel experiments
+if "T41RX_LIB" in os.environ:
+    # an experiment build was asked for BY NAME (tools/build_variant.sh -> t41_sdr_amd/abl/): a library whose kernels
+    # compute wrong results by construction or carry diagnostics refuses t41rx_create() unless the environment says so
+    # (rx_experiments.hpp, rx_host.cpp).  The in-tree product library is never opted in here.
+    os.environ.setdefault("T41RX_ALLOW_EXPERIMENT", "1")
 
 T41RX_OK = 0
 ERR_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_NOMEM, ERR_STATE = -1, -2, -3, -4, -5

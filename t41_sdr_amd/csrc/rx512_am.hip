@@ -1,0 +1,10 @@
+// t41_sdr_amd/csrc/rx512_am.hip -- the rx512_kernel<kModeAm, ...> instantiations (FFT_LENGTH 512, the whole chain fused).
+#include "rx512_launch.hpp"
+
+namespace t41 {
+
+hipError_t launch512_am(const RxArgs &a, hipStream_t s, bool debug) { return launch512<kModeAm>(a, s, debug); }
+
+T41RX_CLK_READER(t41rx_debug_read_clk_am)
+
+}  // namespace t41

@@ -1,0 +1,10 @@
+// t41_sdr_amd/csrc/rx512_ssb.hip -- the rx512_kernel<kModeSsb, ...> instantiations (FFT_LENGTH 512, the whole chain fused).
+#include "rx512_launch.hpp"
+
+namespace t41 {
+
+hipError_t launch512_ssb(const RxArgs &a, hipStream_t s, bool debug) { return launch512<kModeSsb>(a, s, debug); }
+
+T41RX_CLK_READER(t41rx_debug_read_clk)
+
+}  // namespace t41

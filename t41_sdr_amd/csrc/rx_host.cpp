@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "nr_kernels.hpp"
+#include "rx_experiments.hpp"
 #include "rx_internal.hpp"
 #include "rx_kernels.hpp"
 
@@ -376,7 +377,28 @@ int t41rx_design_coeffs(const t41rx_params *p, void *blob, size_t blob_bytes) {
   return design_blob(*p, blob, blob_bytes);
 }
 
+// the product's host side is never an experiment build; what the KERNEL objects were built as is asked at run time
+// (kernel_build_flags(), below): tools/build_variant.sh links this very object with experiment kernels
+static_assert(T41RX_EXPERIMENT == 0 && t41::kKernelBuildFlags == 0, "rx_host.cpp is product code: build it without T41RX_EXPERIMENT / experiment switches");
+
 int t41rx_create(t41rx_ctx **out, int device_id, int n_channels, const t41rx_params *p) {
+  // A library whose kernels were built as a timing experiment computes WRONG RESULTS by construction (rx_experiments.hpp:
+  // -DT41RX_EXPERIMENT=1 with T41RX_ABLATE / _LOO / _AGC_X / _FCABL) and one built with diagnostics writes stamps next to
+  // the samples: neither may stand in for the product by accident.  The tools that time such builds say so in the environment.
+  if (kernel_build_flags() != 0) {
+    const char *allow = std::getenv("T41RX_ALLOW_EXPERIMENT");
+    if (!allow || std::atoi(allow) == 0)
+      return fail(T41RX_ERR_UNSUPPORTED, (kernel_build_flags() & 1)
+                      ? "this libt41rx was built as a timing experiment (wrong results by construction); set T41RX_ALLOW_EXPERIMENT=1 to time it"
+                      : "this libt41rx was built with kernel diagnostics (stamps / counters); set T41RX_ALLOW_EXPERIMENT=1 to use it");
+    static bool warned = false;
+    if (!warned) {
+      warned = true;
+      std::fprintf(stderr, "libt41rx: EXPERIMENT BUILD (kernel_build_flags %d)%s\n", kernel_build_flags(),
+                   (kernel_build_flags() & 1) ? " -- results are WRONG by construction" : " -- diagnostics on");
+    }
+  }
+
   if (!out || !p) return fail(T41RX_ERR_ARG, "null argument");
   *out = nullptr;
   if (n_channels <= 0) return fail(T41RX_ERR_ARG, "n_channels must be > 0");

@@ -1,4 +1,4 @@
-// t41_sdr_amd/csrc/rx_kernels.hpp -- kernel argument block + launcher declaration.
+// t41_sdr_amd/csrc/rx_kernels.hpp -- kernel argument block + launcher declaration (what rx_host.cpp sees of the kernels).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -80,6 +80,9 @@ struct RxArgs {
 constexpr int tab_long_entries(int R) { return (R - 1) * 512 + R * 512; }
 
 hipError_t launch_rx(const RxArgs &a, int fft_length, int mode, hipStream_t s);
+// what the kernel translation units of this library were built as (rx_experiments.hpp; rx_dispatch.hip): 0 = the product,
+// bit 0 = a timing experiment with WRONG RESULTS by construction, bit 1 = a diagnostic build (stamps / counters)
+int kernel_build_flags();
 // FFT_LENGTH 512, behind launch_rx() with aud_out set: interpolators, volume and stores from a.aud24 (f32 or q15 samples out)
 hipError_t launch_back512(const RxArgs &a, hipStream_t s);
 

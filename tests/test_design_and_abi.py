@@ -4,6 +4,7 @@ codes behave, and creating a context without a HIP device fails loudly (no CPU f
 import ctypes as C
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -151,3 +152,36 @@ def test_product_never_touches_the_oracle():
     so = os.path.join(pkg, "libt41rx.so")
     if os.path.exists(so):
         assert "t41oracle" not in subprocess.run(["ldd", so], capture_output=True, text=True).stdout
+
+
+def test_experiment_builds_are_fenced(T, tmp_path):
+    """the timing-experiment switches that make the kernels compute WRONG results (T41RX_ABLATE, _LOO,
+    _AGC_X, _FCABL) and the diagnostic ones sit behind ONE guard (t41_sdr_amd/csrc/rx_experiments.hpp): without
+    -DT41RX_EXPERIMENT=1 they do not compile, and a library built with them refuses t41rx_create() unless the environment
+    opts in.  Checked here with the dispatch translation unit (no kernels: seconds) linked against the product's objects."""
+    import subprocess
+    csrc = os.path.join(ROOT, "t41_sdr_amd", "csrc")
+    base = ["hipcc", "-O1", "-std=c++17", "-fPIC", "-fvisibility=hidden", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include")]
+    for flag in ("-DT41RX_ABLATE=3", "-DT41RX_LOO=2", "-DT41RX_AGC_X=1", "-DT41RX_FCABL=2", "-DT41RX_STAMP", "-DT41RX_CLK"):
+        r = subprocess.run(base + [flag, "-fsyntax-only", "rx_dispatch.hip"], cwd=csrc, capture_output=True, text=True)
+        assert r.returncode != 0 and "T41RX_EXPERIMENT=1" in r.stderr, (flag, r.stderr[-400:])
+    obj = str(tmp_path / "rx_dispatch_exp.o")
+    subprocess.check_call(base + ["-DT41RX_EXPERIMENT=1", "-DT41RX_LOO=2", "-c", "rx_dispatch.hip", "-o", obj], cwd=csrc)
+    objs = [os.path.join(csrc, o) for o in ("rx512_ssb.o", "rx512_am.o", "rx512_nfm.o", "rx512_sam.o", "rx_long.o", "fastconv.o", "display_kernel.o",
+                                            "nr_kernels.o", "rx_host.o", "design.o", "nr_tables.o", "tx_kernels.o", "tx_host.o", "tx_tables.o")]
+    lib_path = str(tmp_path / "libt41rx_exp.so")
+    subprocess.check_call(["hipcc", "-shared", "-fPIC", "--offload-arch=gfx950", obj] + objs + ["-o", lib_path])
+    code = ("import ctypes as C, sys; lib = C.CDLL(%r); lib.t41rx_last_error.restype = C.c_char_p; ctx = C.c_void_p(); "
+            "p = (C.c_int32 * 32)(); lib.t41rx_default_params(p); rc = lib.t41rx_create(C.byref(ctx), 0, 4, p); "
+            "print(rc, lib.t41rx_last_error().decode())" % lib_path)
+    env = {k: v for k, v in os.environ.items() if k != "T41RX_ALLOW_EXPERIMENT"}
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-500:]
+    rc, msg = r.stdout.strip().split(" ", 1)
+    assert int(rc) == -2 and "timing experiment" in msg and "T41RX_ALLOW_EXPERIMENT" in msg   # T41RX_ERR_UNSUPPORTED
+    env["T41RX_ALLOW_EXPERIMENT"] = "1"
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert "EXPERIMENT BUILD" in r.stderr and "WRONG" in r.stderr
+    assert "timing experiment" not in r.stdout   # past the fence (and, without a GPU, on to T41RX_ERR_HIP)
+    # the product library is not one
+    assert T.load().t41rx_abi_version() == 5

@@ -51,7 +51,9 @@ def main():
     lib = _lib.load()
     nw = nch if fft == 512 else 4 * nch  # waves that report (the fused long-FFT kernel runs four per channel)
     buf = (C.c_ulonglong * (4 * nw))()
-    rc = lib.t41rx_debug_read_clk(buf, 4 * nw)
+    # one reader per kernel translation unit (rx_device.hpp: T41RX_CLK_READER)
+    reader = "t41rx_debug_read_clk" + ("_fc" if fft != 512 else {0: "", 1: "", 2: "_am", 3: "_nfm", 8: "_sam"}[kw["mode"]])
+    rc = getattr(lib, reader)(buf, 4 * nw)
     raw = np.frombuffer(buf, dtype=np.uint64).reshape(nw, 4)
     a = raw[:, :2].astype(np.float64)
     if "--dump" in sys.argv:

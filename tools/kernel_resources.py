@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Register / LDS / spill table of every gfx950 kernel in a .hip file (no GPU needed).
 
-usage: python tools/kernel_resources.py [file.hip] [-D...] [--grep REGEX]
+usage: python tools/kernel_resources.py [file.hip ...] [-D...] [--grep REGEX]   (default: every kernel translation unit of t41_sdr_amd/csrc)
 Compiles device-only with -Rpass-analysis=kernel-resource-usage and prints one line per kernel.
 """
 import os
@@ -21,16 +21,23 @@ def main():
         del args[i:i + 2]
     defs = [a for a in args if a.startswith("-")]
     files = [a for a in args if not a.startswith("-")]
-    src = files[0] if files else os.path.join(ROOT, "t41_sdr_amd", "csrc", "rx_kernels.hip")
-    cmd = ["hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fno-slp-vectorize",
-           "--offload-device-only", "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", "/dev/null"] + defs
-    p = subprocess.run(cmd, capture_output=True, text=True, cwd=os.path.dirname(src))
-    if p.returncode != 0:
-        sys.stderr.write(p.stderr)
-        raise SystemExit(p.returncode)
+    csrc = os.path.join(ROOT, "t41_sdr_amd", "csrc")
+    # default: every translation unit of the RX kernels (one per kernel family)
+    srcs = files if files else [os.path.join(csrc, f) for f in ("rx512_ssb.hip", "rx512_am.hip", "rx512_nfm.hip", "rx512_sam.hip", "rx_long.hip",
+                                                               "fastconv.hip", "display_kernel.hip", "nr_kernels.hip")]
+    procs = [subprocess.Popen(["hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fno-slp-vectorize", "-I" + os.path.join(ROOT, "include"),
+                               "--offload-device-only", "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", "/dev/null"] + defs,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=os.path.dirname(os.path.abspath(src))) for src in srcs]
+    err = ""
+    for p in procs:
+        _, e = p.communicate()
+        if p.returncode != 0:
+            sys.stderr.write(e)
+            raise SystemExit(p.returncode)
+        err += e
     cur = None
     rows = []
-    for line in p.stderr.splitlines():
+    for line in err.splitlines():
         m = re.search(r"remark:\s*([A-Za-z /\[\]]+?): (.+?) \[-Rpass", line)
         if not m:
             continue

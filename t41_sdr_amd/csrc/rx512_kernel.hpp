@@ -246,7 +246,7 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
 #ifdef T41RX_PIPE_STAT
     unsigned long long ps_t = __builtin_readcyclecounter();  // [8] front end [9] AGC preparation [10] back end [11] iterations
 #endif
-    if (AGC) PRIO(2); else PRIO(3);  // (AGC on: 3 is the serial chain's, see agc_apply)
+    if (AGC) PRIO(2); else if (T41RX_PRIO_AGE == 2 && KEEP) { if (wv < 8) PRIO(2); else PRIO(3); } else PRIO(3);  // (AGC on: 3 is the serial chain's, see agc_apply)
     FRESH_LANE();
     const bool first_iter = (f == seg0);
     // sample offset of (channel, frame) in I / Q / audio: RxArgs::chan_stride / frame_stride (channel-major
@@ -733,7 +733,12 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
           if (T41RX_LOO == 13) { o1x[0] = o1[0]; o1x[1] = o1[1]; }
         }  // h
         STAMP(4);  // history roll
-        if (rd == 1) { if (AGC) PRIO(1); else PRIO(2); }
+        if (rd == 1) {
+          if (AGC) PRIO(1);
+          else if (T41RX_PRIO_AGE == 1 && KEEP) { if (wv < 8) PRIO(2); else PRIO(3); }
+          else if (T41RX_PRIO_AGE == 2 && KEEP) { if (wv < 8) PRIO(1); else PRIO(2); }
+          else PRIO(2);
+        }
       // ---- decimate by 2 (46 taps) over the 256 new /4 samples: m = 2*lane, 2*lane+1
         wave_sync();
         // y[m] = sum_i c[i] * state[2m + i]; state[i] = buf[i + 3]
@@ -1438,7 +1443,7 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
     }
     wave_sync();
     STAMP(10);  // demod + x2 staging
-    PRIO(0);
+    if (T41RX_PRIO_AGE == 1 && KEEP && !AGC) { if (wv < 8) PRIO(0); else PRIO(1); } else PRIO(0);
     f2 u1[4];  // outputs (2n, 2n+1) of input n = 4 lane + u
     {
       float w[28];

@@ -81,6 +81,12 @@ namespace t41 {
 // rotating over the waves of a SIMD +0.5 %, start offsets between the waves of a CU up to a whole
 // frame period +-0.5 %: the waves spread over the frame by themselves within a few frames.)
 #define PRIO(n) __builtin_amdgcn_s_setprio(n)
+// (round 5, measured and left off: a static bias by wave age.  The arbiter favours the oldest wave of a SIMD; stamps give the
+//  four generations of a 16-wave workgroup lifetimes of 627 / 645 / 664 / 673 us in a 693 us launch, profiles/r05_wave_spread.txt.
+//  1: the younger half one level up in the last two thirds of the frame; 2: the older half one level down in the first two.)
+#ifndef T41RX_PRIO_AGE
+#define T41RX_PRIO_AGE 0
+#endif
 #ifndef T41RX_FRESH
 #define T41RX_FRESH 1
 #endif

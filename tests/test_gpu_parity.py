@@ -227,11 +227,24 @@ def test_agc_min_volts_raised_mid_stream(T, agcmode):
     fast decay where the step-by-step forms do: pipelined == barrier form bit for bit, both within 1e-5 of the oracle
     that makes the same switch."""
     import torch
-    nch, nfr, cut = 37, 16, 6
+    nch, nfr, cut = 37, 20, 6
     nco = siggen.nco_grid(nch, seed=91)
     I, Q = siggen.make_iq(nch, nfr * L, nco, mode=0, seed=92)
-    # loud, then a deep fade (the gain law decays towards the quiet level: states 1..4), then loud again
-    I, Q = siggen.fade(I, Q, [(0.25, 2.5), (0.45, 0.004), (0.3, 1.5)])
+    # loud, then a fade (the gain law decays towards the quiet level: states 1..4), then loud again; the fade starts at a
+    # different instant in every channel -- between 2.6 and 0.1 frames before the parameters change -- so that at the
+    # change the channels sit in every phase of the decay, the fast one (state 1, a few ms long) included.
+    # (A 32 dB step, like the other AGC cases: behind a 50 dB step the quiet frames next to it hold the loud samples'
+    # FFT rounding noise at 4e-5 of their own level IN BOTH implementations -- tools/agc_thresh_probe.py, any AGC_thresh.)
+    steady = np.ones((nch, nfr), bool)  # frames at least one frame away from a step of the channel's envelope
+    steady[:, 0] = False  # power-on: with max_gain 10^4.5 the gain law multiplies the filters' start-up ROUNDING NOISE (the
+    # signal is still inside the 97-sample look-ahead) by up to 3e4 -- 1.4e-7 absolute in both implementations, uncorrelated
+    for c in range(nch):
+        start = (cut - 2.6 + 2.5 * c / (nch - 1)) / nfr
+        e = siggen.envelope_steps(nfr * L, [(start, 2.0), (0.7 - start, 0.05), (0.3, 1.5)])  # quiet until frame 14
+        I[c] = np.clip(I[c] * e, -0.999, 0.999)
+        Q[c] = np.clip(Q[c] * e, -0.999, 0.999)
+        for step in np.flatnonzero(np.diff(e)) // L:  # (the path delays the step by about one frame)
+            steady[c, max(step - 1, 0):step + 3] = False
     kw = dict(mode=0, AGCMode=agcmode, AGC_thresh=90)  # max_gain 10^4.5: min_volts far below the faded level
 
     def run(split_a, split_b):
@@ -245,7 +258,7 @@ def test_agc_min_volts_raised_mid_stream(T, agcmode):
 
     c = cut * L
     pipe, st_p = run([0, c], [c, nfr * L])                                              # two pipelined calls
-    barr, st_b = run([0, 3 * L, c], [c, c + 3 * L, c + 6 * L, c + 9 * L, nfr * L])      # barrier form only (<= 3 frames per call)
+    barr, st_b = run([0, 3 * L, c], [c + 3 * k * L for k in range(5)] + [nfr * L])      # barrier form only (<= 3 frames per call)
     assert np.isfinite(pipe).all()
     assert np.array_equal(pipe, barr)
     assert np.array_equal(st_p, st_b)
@@ -255,7 +268,14 @@ def test_agc_min_volts_raised_mid_stream(T, agcmode):
     ob.redesign()
     r2 = ob.process(np.ascontiguousarray(I[:, c:]), np.ascontiguousarray(Q[:, c:]))
     err = siggen.block_rel_err(pipe, np.concatenate([r1, r2], 1), L)
-    assert err.max() <= TOL, err.max()
+    # Held to 1e-5 in the frames away from the 32 dB steps.  The frames a step runs through hold, next to samples 40 x
+    # smaller, the FFT rounding noise of the loud ones -- in the oracle as in the kernel, at 1e-7 of the LOUD level --
+    # so their block-relative figure says how deep the fade is, not how the two agree: 5e-5 there.  The frames after the
+    # parameter change in which a wrongly kept fast decay would show are steady ones (the quiet stretch behind the fade).
+    assert steady[:, cut + 3:cut + 6].all()
+    where = np.unravel_index(np.where(steady, err, 0).argmax(), err.shape)
+    assert err[steady].max() <= TOL, (err[steady].max(), "channel, frame", where)
+    assert err.max() <= 6e-5, (err.max(), np.unravel_index(err.argmax(), err.shape))
 
 
 def test_agc_mode_change_and_reset(T):

@@ -240,13 +240,17 @@ NR_CASES = {
     "notch": (dict(ANR_notchOn=1), 3e-6, "max"),        # lane-per-channel, the reference's operations in its order: only the
     "lms": (dict(nrOptionSelect=3), 3e-6, "max"),       # interpolators' roundings differ
     "lms+notch": (dict(nrOptionSelect=3, ANR_notchOn=1), 3e-6, "max"),
-    "kim": (dict(nrOptionSelect=1), 2e-5, "max"),       # another FFT and summation order (measured 6e-6; round 3 allowed 1e-4)
+    "kim": (dict(nrOptionSelect=1), 1e-5, "max"),       # another FFT and summation order; round 5: north_star's bar (measured 6.2e-6,
+                                                        # profiles/r05_nr_error_stats.txt; round 4 allowed 2e-5, round 3 1e-4)
     "kim+notch": (dict(nrOptionSelect=1, ANR_notchOn=1), 2e-3, "max"),   # ... fed to the notch from power-on
     # round 4: the smoothing width NN is decided exactly as the scalar code decides it (sums redone in the reference's
     # order next to its thresholds), so no frame takes another NN any more: every frame within 1e-4 (measured 3e-5),
     # 97 % within 1e-5 (round 3: "98.5 % of the frames within 1e-3")
-    "spectral": (dict(nrOptionSelect=2), 1e-4, "most"),
-    "spectral-am-agc": (dict(nrOptionSelect=2, mode=2, FLoCut=-3000, FHiCut=3000, AGCMode=2), 1e-4, "most"),
+    # round 5: every frame within 5e-5 (measured 2.8e-5), 99 % within 1e-5; on the same input the ORACLE sits as far from
+    # the float64 model as the kernel does (test_gpu_stage_is_as_close_to_the_exact_model_as_the_oracle): the tail is the
+    # function's conditioning (it divides by small noise estimates), not the kernel's arithmetic
+    "spectral": (dict(nrOptionSelect=2), 5e-5, "most"),
+    "spectral-am-agc": (dict(nrOptionSelect=2, mode=2, FLoCut=-3000, FHiCut=3000, AGCMode=2), 2e-5, "most"),
 }
 
 
@@ -278,7 +282,8 @@ def test_gpu_stage_in_isolation(built, name):
     if how == "max":
         assert e.max() <= tol, "worst %.3e at %s" % (e.max(), np.unravel_index(e.argmax(), e.shape))
     else:
-        assert e.max() <= tol and (e < 1e-5).mean() > 0.97 and np.median(e) < 5e-6, ((e < 1e-5).mean(), np.median(e), e.max())
+        assert e.max() <= tol and (e < 1e-5).mean() > 0.985 and np.median(e) < 2e-6, (
+            "per frame: <= 1e-5 on %.2f %%, median %.1e, p99 %.1e, max %.1e" % (100 * (e < 1e-5).mean(), np.median(e), np.percentile(e, 99), e.max()))
 
 
 def _exact_stage_and_interpolators(pre, kw):
@@ -362,7 +367,8 @@ def test_gpu_whole_path_with_nr(built, name):
     b = rx.ProcessIQData(dI[:, 4 * L:].contiguous(), dQ[:, 4 * L:].contiguous()).cpu().numpy()
     rb = ob.process(I[:, 4 * L:], Q[:, 4 * L:])
     e = siggen.block_rel_err(np.concatenate([a, b], axis=1), np.concatenate([ra, rb], axis=1), L)
-    tol = {"notch-late": 1e-5, "lms": 1e-5, "kim": 2e-5, "spectral": 1e-4}[name]  # (round 3: 5e-5, 1e-5, 1e-4, "97 % within 1e-3")
+    # round 5: Kim at north_star's 1e-5 (measured 7.2e-6), spectral 5e-5 (measured 2.8e-5; 93 % of frames within 1e-5)
+    tol = {"notch-late": 1e-5, "lms": 1e-5, "kim": 1e-5, "spectral": 5e-5}[name]  # (round 4: 1e-5, 1e-5, 2e-5, 1e-4)
     assert e.max() <= tol, e.max(axis=0)
     if name == "spectral":
         assert (e < 1e-5).mean() > 0.85 and np.median(e) < 5e-6, ((e < 1e-5).mean(), np.median(e))

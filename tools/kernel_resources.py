@@ -23,7 +23,7 @@ def main():
     files = [a for a in args if not a.startswith("-")]
     csrc = os.path.join(ROOT, "t41_sdr_amd", "csrc")
     # default: every translation unit of the RX kernels (one per kernel family)
-    srcs = files if files else [os.path.join(csrc, f) for f in ("rx512_ssb.hip", "rx512_am.hip", "rx512_nfm.hip", "rx512_sam.hip", "rx_long.hip",
+    srcs = [os.path.abspath(f) for f in files] if files else [os.path.join(csrc, f) for f in ("rx512_ssb.hip", "rx512_am.hip", "rx512_nfm.hip", "rx512_sam.hip", "rx_long.hip",
                                                                "fastconv.hip", "display_kernel.hip", "nr_kernels.hip")]
     procs = [subprocess.Popen(["hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fno-slp-vectorize", "-I" + os.path.join(ROOT, "include"),
                                "--offload-device-only", "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", "/dev/null"] + defs,

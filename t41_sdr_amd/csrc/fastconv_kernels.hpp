@@ -427,7 +427,7 @@ __global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_fuse
   static_assert(NWV == 4 && H == 2, "written for four waves per channel");
   static_assert(NWV * kLdsFloatsPerWave <= 2 * kFcRow * R, "the front end's slices fit in the working array");
   int lane = threadIdx.x & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // (re-defined per phase like `lane`, see FRESH_WV)
   const int ch = blockIdx.x;
   if (ch >= a.nchan) return;
   T41RX_CLK_BEGIN();
@@ -498,7 +498,7 @@ __global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_fuse
   const float *gQc = a.Q + (size_t)ch * a.nframes * L;
 
   for (int f = 0; f < a.nframes4k; ++f) {
-    FRESH_LANE();
+    FRESH_LANE(); FRESH_WV(wv);
 #if T41RX_FC_PRIO
     switch ((4 * f) / a.nframes4k) {
       case 0: PRIO(3); break;
@@ -709,7 +709,7 @@ __global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_fuse
       }
     }
     __syncthreads();  // every wave is done with its slice: the array takes the new block in time order
-    FRESH_LANE();
+    FRESH_LANE(); FRESH_WV(wv);
     {
       cf *Nb = reinterpret_cast<cf *>(smem);  // new block: sample n = 256 s + m at Nb[n]
 #pragma unroll
@@ -731,7 +731,7 @@ __global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_fuse
       }
       load_twp();
       __syncthreads();  // the new block is in registers everywhere: pass 1 may write the array
-      FRESH_LANE();
+      FRESH_LANE(); FRESH_WV(wv);
       // ---- pass 1
 #pragma unroll
       for (int h = 0; h < H; ++h) {
@@ -760,7 +760,7 @@ __global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_fuse
       for (int r = 0; r < 8; ++r) mk[h][r] = maskN[512 * q + lane + 64 * r];
     }
     __syncthreads();
-    FRESH_LANE();
+    FRESH_LANE(); FRESH_WV(wv);
     // ---- pass 2
     if (T41RX_FF_X2) {
       const int q0 = wv, q1 = wv + NWV;
@@ -802,7 +802,7 @@ __global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_fuse
     }
     load_twp();
     __syncthreads();
-    FRESH_LANE();
+    FRESH_LANE(); FRESH_WV(wv);
     // ---- pass 3; fixed gain (DSP_Fn.cpp:494-502); SSB: audio = Re of the valid half
     float y3[H][R / 2];
 #pragma unroll
@@ -821,7 +821,7 @@ __global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_fuse
       float ci[48];
       load_taps<48>(ci, (CFloatPtr)cf0, kCoInt1);
       __syncthreads();
-      FRESH_LANE();
+      FRESH_LANE(); FRESH_WV(wv);
 #pragma unroll
       for (int h = 0; h < H; ++h)
 #pragma unroll
@@ -829,7 +829,7 @@ __global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_fuse
       if (threadIdx.x < 24) AU[threadIdx.x] = hi_reg;
       if (threadIdx.x < 8) YT[threadIdx.x] = yt_reg;
       __syncthreads();
-      FRESH_LANE();
+      FRESH_LANE(); FRESH_WV(wv);
       if (threadIdx.x < 24) hi_reg = AU[D + threadIdx.x];
       f2 u1[H][4];
 #pragma unroll
@@ -863,7 +863,7 @@ __global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_fuse
       float c4[32];
       load_taps<32>(c4, (CFloatPtr)cf0, kCoInt2);
       __syncthreads();
-      FRESH_LANE();
+      FRESH_LANE(); FRESH_WV(wv);
       if (f == a.nframes4k - 1) {
         if (threadIdx.x < 24) st[kStInt1 + threadIdx.x] = hi_reg;
         else if (threadIdx.x >= 64 && threadIdx.x < 72) st[kStInt2 + threadIdx.x - 64] = YT[8 * R + threadIdx.x - 64];

@@ -450,7 +450,11 @@ __device__ __forceinline__ lanemask agc_block_phased(AgcState &st, AgcLane &d, c
       // min_volts (a live set_params / set_coeffs raised it, or a restored checkpoint) is lifted to it at step 0, so
       // vin[0] may sit at or below the threshold while vin[1..3] = min_volts sit above it; once clamped the three are
       // equal, so the first and the last comparison cover every step
+#if T41RX_AGC_R04CHECK  // (experiment build: round 4's unsound short-cut, to show that the tests and the soak catch it)
+      ok &= lanes_gt(vin[3], d.thr);
+#else
       ok &= lanes_gt(vin[0], d.thr) & lanes_gt(vin[3], d.thr);
+#endif
     } else {
       lanemask in0 = d.in0, pend = d.pend;
       float save_volts = st.save_volts;

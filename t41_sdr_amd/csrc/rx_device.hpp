@@ -99,6 +99,17 @@ namespace t41 {
 #else
 #define FRESH_LANE() do {} while (0)
 #endif
+// The same for the wave index (round 5, the long-FFT one-kernel form): hipcc hoists every `row base + k * 0x100` derived from it out
+// of the frame loop as a loop invariant, runs out of SGPRs, spills the lot to VGPR lanes and reads each back with a
+// v_readlane_b32 -- a VALU instruction for what one s_add_i32 recomputes for free.
+#ifndef T41RX_FRESH_WV
+#define T41RX_FRESH_WV 1
+#endif
+#if T41RX_FRESH_WV
+#define FRESH_WV(w) asm volatile("" : "+s"(w))
+#else
+#define FRESH_WV(w) do {} while (0)
+#endif
 
 // Diagnostic build only (-DT41RX_STAMP): s_memtime stamps at phase boundaries; lane p of each wave
 // accumulates the cycles of phase p and writes them behind the demod debug tap at the end.

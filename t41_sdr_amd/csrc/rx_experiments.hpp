@@ -15,6 +15,8 @@
 //     T41RX_LOO = n      (leave one out) cuts exactly stage n of that list and keeps every other one; 13 / 14: the /2 / the
 //                        /4 decimator's window taken from registers instead of LDS
 //     T41RX_AGC_X        bit mask: 1 no back-averages, 2 no bookkeeping, 4 no bracket in the pipelined AGC chain's block
+//     T41RX_AGC_R04CHECK 1: round 4's per-block fast-decay check of the pipelined AGC chain (unsound when min_volts was raised
+//                        under a decaying lane) -- to show that tests/ and tools/pipe_soak.py catch it
 //     T41RX_FCABL        bit mask: 1 no output stores, 2 no 512-point FFTs, 4 no input loads, 8 no x4 arithmetic, 16 no x2
 //                        arithmetic in the long-FFT kernels
 //   diagnostics (results unchanged, extra stores / counters)
@@ -38,16 +40,19 @@
 #ifndef T41RX_FCABL
 #define T41RX_FCABL 0
 #endif
+#ifndef T41RX_AGC_R04CHECK
+#define T41RX_AGC_R04CHECK 0
+#endif
 #define T41RX_CUT(n) ((T41RX_ABLATE >= (n) && T41RX_ABLATE <= 8) || T41RX_LOO == (n))
 
-#define T41RX_WRONG_RESULTS (T41RX_ABLATE != 0 || T41RX_LOO != 0 || T41RX_AGC_X != 0 || T41RX_FCABL != 0)
+#define T41RX_WRONG_RESULTS (T41RX_ABLATE != 0 || T41RX_LOO != 0 || T41RX_AGC_X != 0 || T41RX_FCABL != 0 || T41RX_AGC_R04CHECK != 0)
 #if defined(T41RX_STAMP) || defined(T41RX_PIPE_STAT) || defined(T41RX_CLK)
 #define T41RX_DIAGNOSTICS 1
 #else
 #define T41RX_DIAGNOSTICS 0
 #endif
 #if (T41RX_WRONG_RESULTS || T41RX_DIAGNOSTICS) && !T41RX_EXPERIMENT
-#error "T41RX_ABLATE / _LOO / _AGC_X / _FCABL / _STAMP / _PIPE_STAT / _CLK are experiment builds: pass -DT41RX_EXPERIMENT=1 with them (rx_experiments.hpp)"
+#error "T41RX_ABLATE / _LOO / _AGC_X / _AGC_R04CHECK / _FCABL / _STAMP / _PIPE_STAT / _CLK are experiment builds: pass -DT41RX_EXPERIMENT=1 with them (rx_experiments.hpp)"
 #endif
 
 namespace t41 {

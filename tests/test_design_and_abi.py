@@ -162,7 +162,7 @@ def test_experiment_builds_are_fenced(T, tmp_path):
     import subprocess
     csrc = os.path.join(ROOT, "t41_sdr_amd", "csrc")
     base = ["hipcc", "-O1", "-std=c++17", "-fPIC", "-fvisibility=hidden", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include")]
-    for flag in ("-DT41RX_ABLATE=3", "-DT41RX_LOO=2", "-DT41RX_AGC_X=1", "-DT41RX_FCABL=2", "-DT41RX_STAMP", "-DT41RX_CLK"):
+    for flag in ("-DT41RX_ABLATE=3", "-DT41RX_LOO=2", "-DT41RX_AGC_X=1", "-DT41RX_AGC_R04CHECK=1", "-DT41RX_FCABL=2", "-DT41RX_STAMP", "-DT41RX_CLK"):
         r = subprocess.run(base + [flag, "-fsyntax-only", "rx_dispatch.hip"], cwd=csrc, capture_output=True, text=True)
         assert r.returncode != 0 and "T41RX_EXPERIMENT=1" in r.stderr, (flag, r.stderr[-400:])
     obj = str(tmp_path / "rx_dispatch_exp.o")

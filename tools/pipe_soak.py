@@ -21,7 +21,7 @@ def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
     rng = np.random.default_rng(int(time.time()))
     g = torch.Generator(device="cuda").manual_seed(int(rng.integers(1 << 30)))
-    t0, runs, frames, bad, nonfinite, nan_payload = time.time(), 0, 0, [], 0, 0
+    t0, runs, frames, bad, nonfinite, nan_payload, changed = time.time(), 0, 0, [], 0, 0, 0
     while time.time() - t0 < budget:
         big = runs % 25 == 24
         nch = 4096 if big else int(rng.choice([1, 2, 3, 5, 15, 16, 17, 31, 33, 64, 100, 255, 256, 300, 1000]))
@@ -39,13 +39,29 @@ def main():
         if q15:
             I = (I * 32768.0).round_().clamp_(-32768, 32767).to(torch.int16)
             Q = (Q * 32768.0).round_().clamp_(-32768, 32767).to(torch.int16)
+        # round 5: in a third of the runs with the AGC on, AGC_thresh changes mid-stream (a live CalcFilters(): min_volts
+        # jumps up or down under lanes in their decay states -- the case ADVICE r04 found the per-block short-cut unsound for)
+        cutf, thr0, thr1 = None, 20, 20
+        if agc and nfr >= 8 and rng.random() < 0.34:
+            cutf = int(rng.integers(4, nfr - 3))
+            thr0, thr1 = int(rng.integers(-20, 91)), int(rng.integers(-20, 91))
+            kw["AGC_thresh"] = thr0
         rx1 = T.RxChain(nch, T.default_params(**kw), NCOFreq=nco)
         run = (lambda rx, a, b: rx.ProcessIQData_q15(b, a)) if q15 else (lambda rx, a, b: rx.ProcessIQData(a, b))
-        whole = run(rx1, I, Q)
+        if cutf is None:
+            whole = run(rx1, I, Q)
+        else:  # two pipelined calls (>= 4 frames each) around the change
+            w1 = run(rx1, I[:, :cutf * L].contiguous(), Q[:, :cutf * L].contiguous())
+            rx1.CalcFilters(AGC_thresh=thr1)
+            whole = torch.cat([w1, run(rx1, I[:, cutf * L:].contiguous(), Q[:, cutf * L:].contiguous())], dim=1)
         rx2 = T.RxChain(nch, T.default_params(**kw), NCOFreq=nco)
         parts, pos = [], 0
         while pos < nfr:
             n = min(int(rng.integers(1, 4)), nfr - pos)
+            if cutf is not None and pos < cutf:
+                n = min(n, cutf - pos)
+            if cutf is not None and pos == cutf:
+                rx2.CalcFilters(AGC_thresh=thr1)
             parts.append(run(rx2, I[:, pos * L:(pos + n) * L].contiguous(), Q[:, pos * L:(pos + n) * L].contiguous()))
             pos += n
         short = torch.cat(parts, dim=1)
@@ -70,11 +86,12 @@ def main():
             bad.append(dict(run=runs, nch=nch, nfr=nfr, kw=kw, same=same, finite=finite))
             print("MISMATCH", bad[-1], flush=True)
         runs += 1
+        changed += 0 if cutf is None else 1
         frames += nch * nfr
         del rx1, rx2, I, Q, env, whole, short, parts
         if runs % 20 == 0:
             print("%d runs, %.1f M channel-frames, %d mismatches, %.0f s" % (runs, frames / 1e6, len(bad), time.time() - t0), flush=True)
-    print(json.dumps({"runs": runs, "channel_frames": frames, "mismatches": len(bad), "runs_with_nonfinite_samples": nonfinite, "runs_whose_checkpoints_differ_in_nan_payloads_only": nan_payload,
+    print(json.dumps({"runs": runs, "channel_frames": frames, "runs_with_AGC_thresh_changed_mid_stream": changed, "mismatches": len(bad), "runs_with_nonfinite_samples": nonfinite, "runs_whose_checkpoints_differ_in_nan_payloads_only": nan_payload,
                       "seconds": round(time.time() - t0, 1)}), flush=True)
     sys.exit(1 if bad else 0)
 

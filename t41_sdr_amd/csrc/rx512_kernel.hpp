@@ -912,7 +912,12 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
   #pragma unroll
           for (int rd = 0; rd < 2; ++rd) {
             const int m0 = 128 * rd + 2 * lane;  // my samples m0, m0 + 1 share the window in[m0 .. m0 + 81]
-            float acc0 = 0.0f, acc1 = 0.0f;      // taps in ascending order, separate multiply and add, as the reference's loop
+            // taps in ascending order, separate multiply and add, as the reference's loop.  Round 5: the two outputs of a
+            // lane ride in ONE register pair -- step k multiplies in[m0 + k] by (taps[k], taps[k - 1]), a v_pk_mul_f32 and a
+            // v_pk_add_f32 where there were two multiplies and two adds (same operations on the same values in the same
+            // order; a tap that does not exist is a zero, whose product leaves its sum as it is): 656 -> 328 VALU
+            // instructions per frame
+            f2 acc = splat(0.0f);  // (acc0, acc1)
             float tp[96];
   #pragma unroll
             for (int c = 0; c < 96; c += 16) {
@@ -924,14 +929,17 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
               for (int jj = c / 2; jj < c / 2 + 8; ++jj) {
                 if (2 * jj > kDeemphTaps) continue;  // pairs (in[m0 + 2 jj], in[m0 + 2 jj + 1]), jj = 0..40
                 const float2 w = *reinterpret_cast<const float2 *>(ds + m0 + 2 * jj);
-                if (2 * jj < kDeemphTaps) acc0 += tp[2 * jj] * w.x;
-                if (jj > 0) acc1 += tp[2 * jj - 1] * w.x;
-                if (2 * jj + 1 < kDeemphTaps) acc0 += tp[2 * jj + 1] * w.y;
-                if (2 * jj < kDeemphTaps) acc1 += tp[2 * jj] * w.y;
+                static_assert(kDeemphTaps == 81, "2 jj <= 80 below: tap 2 jj always exists");
+                const float t_m1 = (jj > 0) ? tp[2 * jj - 1] : 0.0f;
+                const float t_p1 = (2 * jj + 1 < kDeemphTaps) ? tp[2 * jj + 1] : 0.0f;
+                f2 pr = f2{tp[2 * jj], t_m1} * splat(w.x);
+                acc = acc + pr;
+                pr = f2{t_p1, tp[2 * jj]} * splat(w.y);
+                acc = acc + pr;
               }
             }
-            au[rd][0] = (m0 < D - kDeemphTaps) ? acc0 : y2[rd][0].y;
-            au[rd][1] = (m0 + 1 < D - kDeemphTaps) ? acc1 : y2[rd][1].y;
+            au[rd][0] = (m0 < D - kDeemphTaps) ? acc.x : y2[rd][0].y;
+            au[rd][1] = (m0 + 1 < D - kDeemphTaps) ? acc.y : y2[rd][1].y;
           }
           wave_sync();
         }

@@ -278,6 +278,49 @@ def test_agc_min_volts_raised_mid_stream(T, agcmode):
     assert err.max() <= 6e-5, (err.max(), np.unravel_index(err.argmax(), err.shape))
 
 
+@pytest.mark.parametrize("agcmode", [1, 2, 4])
+def test_agc_restored_below_min_volts_in_fast_decay(T, agcmode):
+    """ADVICE r04's case made deterministic: a restored checkpoint puts every channel in the fast decay (state 1) with
+    volts <= save_volts < min_volts.  DSP_Fn.cpp:579-594 leaves the fast decay at the very first step (volts is not above
+    save_volts) -- to the hang, the slow or the hang decay, by hang counter and decay type -- and :629 then lifts volts to
+    min_volts.  A short-cut that looks at the last step of a four-step block only sees min_volts > save_volts and keeps
+    the lane in state 1 (round 4's did: tools/build_variant.sh r04check -DT41RX_AGC_R04CHECK=1 fails this test, and
+    tools/pipe_soak.py finds it within seconds).  Pipelined form == barrier form, outputs and checkpoints."""
+    import torch
+    nch, nfr = 37, 12
+    nco = siggen.nco_grid(nch, seed=191)
+    I, Q = siggen.make_iq(nch, nfr * L, nco, mode=0, seed=192)
+    I[:, :4 * L] = 0.0  # four frames of silence: no attack while the restored state plays out, then signal
+    Q[:, :4 * L] = 0.0
+    kw = dict(mode=0, AGCMode=agcmode)  # AGC_thresh 20: min_volts 0.0654
+
+    def run(split):
+        rx = T.RxChain(nch, T.default_params(**kw), NCOFreq=nco)
+        ck = rx.get_state()
+        rec = rx.state_records(ck)            # a view into ck
+        w = rec[:, -8:]                       # rx_internal.hpp kAgcSt*: fast / hang back-average, volts, save_volts, state, decay type, hang counter
+        w[:, 2] = 0.01
+        w[:, 3] = 0.02
+        wi = w.view(np.int32)
+        wi[:, 4] = 1
+        wi[:, 5] = np.arange(nch) % 2
+        wi[:, 6] = np.where(np.arange(nch) % 3 == 0, 40, 0)
+        rx.set_state(ck)
+        dI, dQ = torch.from_numpy(I).cuda(), torch.from_numpy(Q).cuda()
+        out = torch.cat([rx.ProcessIQData(dI[:, a:b].contiguous(), dQ[:, a:b].contiguous()) for a, b in zip(split[:-1], split[1:])], dim=1)
+        torch.cuda.synchronize()
+        return out.cpu().numpy(), rx.get_state(), rx.state_records()[:, -8:].view(np.int32)[:, 4].copy()
+
+    pipe, st_p, states_p = run([0, 6 * L, nfr * L])                  # two pipelined calls
+    barr, st_b, states_b = run([k * L for k in range(nfr + 1)])      # one frame per call: the barrier form
+    mid_p = run([0, 6 * L])[2]                                       # the state words after the silence + two frames
+    mid_b = run([k * L for k in range(7)])[2]
+    assert np.isfinite(pipe).all() and np.abs(pipe[:, 6 * L:]).max() > 0
+    assert np.array_equal(mid_p, mid_b), (mid_p, mid_b)
+    assert np.array_equal(pipe, barr)
+    assert np.array_equal(st_p, st_b)
+
+
 def test_agc_mode_change_and_reset(T):
     """AGCMode is a parameter like the filter edges: switching it mid-stream keeps the delay line and
     the gain state (the firmware only re-runs AGCLoadValues()), reset() returns to power-on"""

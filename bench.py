@@ -97,7 +97,7 @@ KERNEL_SOURCES = tuple("t41_sdr_amd/csrc/" + f for f in (
 # what the default run times behind the headline (N = 1): every mode and sample format the README claims, each replayed
 # against the oracle, and the headline workload in the firmware's own calling shape (1 frame per call) and at 4 frames
 OTHER_WORKLOADS = ("nfm", "nfm_atan", "am", "sam", "fft4096", "ssb_agc", "ssb_q15", "ssb_agc_q15", "sam_agc", "ssb_time_major",
-                   "ssb_1fpl", "ssb_4fpl")
+                   "ssb_1fpl", "ssb_4fpl", "ssb_kim", "ssb_spectral", "ssb_notch")
 
 
 def kernel_source_hash():
@@ -452,8 +452,7 @@ def main():
         # the timed stream against the CPU oracle, in the timed launch shape (replayed: see parity_check)
         # (the noise-reduction workloads start their adaptive stages on the path's start-up transient: their parity is
         # the business of tests/test_noise_reduction.py, which feeds both sides identical audio)
-        nr = head.params_kw.get("nrOptionSelect", 0) or head.params_kw.get("ANR_notchOn", 0)
-        if not os.environ.get("T41RX_BENCH_NOCHECK") and not nr:
+        if not os.environ.get("T41RX_BENCH_NOCHECK") and not head.params_kw.get("ANR_notchOn", 0):
             line["parity_check"] = parity_check(torch, head, min(args.warmup + args.steps, 160), args.warmup + args.steps)
         if world == 1 and not args.no_cpu_baseline and args.workload == "ssb":
             line["cpu_baseline"] = cpu_baseline(torch, head.Is, head.Qs, head.nco, head.params_kw, head.n, head.frame_len)
@@ -470,7 +469,14 @@ def main():
             entry = {"workload": w.wl["name"], "batch": w.n, "frames_per_launch": w.frames, "steps": wsteps, "warmup": wwarm,
                      "kernel_ms": r["kernel_ms"], "us_per_frame": r["us_per_frame"], "frac": r["frac"], "achieved_GBs": r["achieved"],
                      "traffic": r["traffic"], "dtype": "f32" if not w.q15 else "f32 (q15 samples in and out)"}
-            if not os.environ.get("T41RX_BENCH_NOCHECK"):
+            if w.params_kw.get("ANR_notchOn", 0):
+                # the automatic notch from power-on adapts on the front end's start-up transient -- samples of 1e-7 whose power it
+                # divides by: two f32 front ends that agree to 1e-7 leave it 1e-2 apart for tens of frames, the oracle against its
+                # own perturbed self included (tests/test_noise_reduction.py::test_oracle_stage_conditioning); its parity is held
+                # in isolation (3e-6) and from a running stream (1e-5) by the tests, not by a replay from power-on
+                entry["parity_check"] = None
+                entry["parity_note"] = "timed only: the notch from power-on is ill-conditioned in any arithmetic (DESIGN.md 4.10); tests hold it in isolation"
+            elif not os.environ.get("T41RX_BENCH_NOCHECK"):
                 # every launch of this workload's run (warm-up + timed), replayed and compared with the oracle; the
                 # replay must reproduce the timed pass bit for bit (round 3 checked 2 of the 16 and could not assert that)
                 entry["parity_check"] = parity_check(torch, w, wwarm + wsteps, wwarm + wsteps, sample=8 if w.fft_length == 4096 else 16)
@@ -653,14 +659,20 @@ def parity_check(torch, w, launches, launches_timed, sample=16):
         sq_ref += float((ref ** 2).sum())
     ob.close()
     # the stated bars: 1e-5 (north_star); AM 5e-5 (the reference's f32 DC blocker, tests/test_gpu_parity.py::test_parity_am); q15 +-1 LSB
-    tol = 1.0 / 32768.0 + 1e-9 if w.q15 else (5e-5 if w.params_kw.get("mode") == 2 else 1e-5)
+    # The noise-reduction stages, WHOLE PATH from power-on (the two sides' stage inputs differ by the front ends' 1e-7): the bars
+    # are the stages' own conditioning, measured on the oracle against its own 1e-7-perturbed self
+    # (tests/test_noise_reduction.py::test_oracle_stage_conditioning) -- Kim's gain 1 - M / E cancels where the
+    # noise is stationary, as on this workload's tones: 1e-4; the spectral function: 5e-5, and its integer smoothing width flips
+    # in isolated frames (allowed: 1 frame in 1000).  On IDENTICAL stage input the tests hold them to 1e-5 / 5e-5.
+    nr_opt = w.params_kw.get("nrOptionSelect", 0)
+    tol = 1.0 / 32768.0 + 1e-9 if w.q15 else (1e-4 if nr_opt == 1 else 5e-5 if (w.params_kw.get("mode") == 2 or nr_opt == 2) else 1e-5)
     over = int(sum(int((r > tol).sum()) for r in rels))
     frames = int(sum(r.size for r in rels))
     # nfm_demod = 1: ApproxAtan2 as written (Demod.cpp:176-193: 2 pi where pi / 2 is meant) JUMPS by 3 pi / 2 where |x| = |y|,
     # so two f32 evaluations whose (x, y) differ in the last bit take different branches about once per million samples
     # (this check replays ~2 million): such a frame differs grossly in ANY pair of implementations.  Allowed: 1 frame in
     # 1000, counted and reported; every other frame meets the bar.
-    allowed = frames // 1000 if w.params_kw.get("nfm_demod") else 0
+    allowed = frames // 1000 if (w.params_kw.get("nfm_demod") or nr_opt == 2) else 0
     ok = (bool(worst <= tol) or over <= allowed) and replay_identical is not False
     return {"ok": ok, "max_block_rel_err": worst, "tolerance": tol, "at_launch_frame_channel": worst_at,
             "frames_checked": frames, "frames_over_tolerance": over, "frames_over_tolerance_allowed": allowed,

@@ -12,6 +12,9 @@ OUT="$ROOT/gpurun_out/profile_$TAG"
 mkdir -p "$OUT"
 export T41RX_BENCH_NOCHECK=1   # (the parity replay is bench.py's own business; here only the timed launches' kernels count)
 cd /tmp
+# one un-profiled run first: a fresh box's first seconds of load (clock / power management settling, first-touch of the
+# allocator) otherwise land in the first workload's trace (round 5: 782 us +- 82 per launch there, 693 in the bench minutes later)
+python3 "$ROOT/bench.py" --no-other-workloads --workload ssb --steps 200 --warmup 20 --no-cpu-baseline > $OUT/settle.log 2>&1
 for W in $WL; do
   echo "== $W"
   timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$W/trace -o t -- python3 "$ROOT/bench.py" --no-other-workloads --workload $W --steps 30 --warmup 5 --no-cpu-baseline > $OUT/$W.trace.log 2>&1 || echo "trace $W failed"

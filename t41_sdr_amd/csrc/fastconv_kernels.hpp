@@ -411,8 +411,13 @@ __global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_kern
 #ifndef T41RX_FF_PF
 #define T41RX_FF_PF 1  // input sub-blocks in flight ahead of the one being worked on (1: one register set, 2: two)
 #endif
+// Round 5: with the tap pointers laundered at their base and the wave-index offsets re-derived per phase (FRESH_WV) the
+// kernel spills 40 SGPRs instead of 85, and the balance tips: the previous block IN REGISTERS (12 VGPRs spilled, 36 B of
+// scratch per lane that stay in L2) measures 51.4-51.6 against 53.1-53.3 us per frame interleaved on one box, and the fabric
+// traffic falls from 1.153 to 1.077 x the algorithmic bytes (the 16 KiB round trip through the record is gone):
+// profiles/r05_ab_prevreg.txt.  (Round 3, 85 spilled SGPRs, two sub-blocks in flight: 56.4 against 54.2 the other way.)
 #ifndef T41RX_FF_PREV_GLOBAL
-#define T41RX_FF_PREV_GLOBAL 1  // the "previous" block waits in the channel's record (L2) instead of 16 registers per lane
+#define T41RX_FF_PREV_GLOBAL 0  // 1: the "previous" block waits in the channel's record (L2) instead of 16 registers per lane
 #endif
 typedef float f2n __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ cf ldg_stream2(const cf *p) {  // 8-byte load that does not look at this CU's L1

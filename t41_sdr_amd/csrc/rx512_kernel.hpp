@@ -194,6 +194,8 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
   float hist2c = 0.0f, audn[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   float4 agrec = make_float4(0, 0, 0, 0);  // PIPE: the AGC's delay line (its last 100 inputs), lanes 0..49, across the frames of a launch
   float2 agmag = make_float2(0, 0);        // ... and its magnitudes
+  // PIPE, SSB / NFM (T41RX_PIPE_KEEP_RE): the popped samples' real parts of the three frames between preparation and gain
+  float4 zre0 = make_float4(0, 0, 0, 0), zre1 = zre0, zre2 = zre0;
 #ifdef T41RX_STAMP
   unsigned long long stamp_acc = 0, stamp_last;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
@@ -1150,6 +1152,7 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
         const int nvalid = left < NW ? left : NW;
         unsigned *flags = reinterpret_cast<unsigned *>(smem) + kPipeFlags;
         constexpr bool NEED_IM = (MODE == kModeAm);
+        constexpr bool KEEP_RE = T41RX_PIPE_KEEP_RE && !NEED_IM && !PSAM;  // re(f - 2) = zre2 here, re(f) -> zre0 below
         unsigned long long *pipe_stat = reinterpret_cast<unsigned long long *>(a.agc_pipe + (size_t)a.nchan * kPipeSlots * kPipeSlotFloats) + (size_t)job * 16;
         (void)pipe_stat;
         unsigned *pipe_err = reinterpret_cast<unsigned *>(reinterpret_cast<unsigned long long *>(a.agc_pipe + (size_t)a.nchan * kPipeSlots * kPipeSlotFloats) +
@@ -1172,14 +1175,14 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
         if (early) {
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
           if (PSAM) gin.vv = *reinterpret_cast<const float4 *>(bslot + 512 + 4 * lane);  // the frame's audio
-          else gin = agc_gain_request<NEED_IM>(bslot, lane);
+          else gin = agc_gain_request<NEED_IM, KEEP_RE>(bslot, lane, zre2);
         }
         if (f < seg1) {  // this frame's chain operands and popped samples -> the channel's slot
           float *pslot = a.agc_pipe + ((size_t)ch * kPipeSlots + f % kPipeSlots) * kPipeSlotFloats;
           if (PSAM) sam_prep_pipe(v, fixed_gain, pslot, lane);
           else {
             if (first_iter) agmag = make_float2(agc_mag(cf{agrec.x, agrec.y}), agc_mag(cf{agrec.z, agrec.w}));  // (later frames: carried)
-            agrec = agc_prep_pipe<AgcLds<true>, NEED_IM>(v, agrec, agmag, lds, pslot, cf0, lane);
+            agrec = agc_prep_pipe<AgcLds<true>, NEED_IM, KEEP_RE>(v, agrec, agmag, lds, pslot, cf0, lane, &zre0);
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
           if (lane == 0) __hip_atomic_fetch_add(flags + f % kPipeSlots, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1187,6 +1190,12 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
           if (lane == 0) pipe_stat[9] += __builtin_readcyclecounter() - ps_t;
 #endif
         }
+        const float4 re_gain = zre2;  // the gain below works on frame f - 2 ...
+        if (KEEP_RE) {                // ... and the ring moves on for the next iteration (every iteration, also the first two)
+          zre2 = zre1;
+          zre1 = zre0;
+        }
+        (void)re_gain;
         const int g = f - 1;  // the frame whose chain is due
 #if T41RX_PIPE_CLAIM
         // the duty goes to the first wave that gets here (the one furthest ahead: it is sure to be waiting when the previous
@@ -1232,7 +1241,7 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
           pipe_wait_ge(flags + 3, (unsigned)(fb + 1), pipe_err);
           PIPE_STAT_ADD(3);
           if (PSAM) gin.vv = *reinterpret_cast<const float4 *>(bslot + 512 + 4 * lane);
-          else gin = agc_gain_request<NEED_IM>(bslot, lane);
+          else gin = agc_gain_request<NEED_IM, KEEP_RE>(bslot, lane, re_gain);
         }
 #ifdef T41RX_PIPE_STAT
         ps_t = __builtin_readcyclecounter();

@@ -834,9 +834,21 @@ __device__ __forceinline__ void pipe_wait_ge(const unsigned *p, unsigned target,
 }
 
 // first half of agc_apply: magnitudes, look-ahead maxima; what the chain and the gain need -> slot
-template <typename AL, bool NEED_IM>
+// Round 5, measured and left off (T41RX_PIPE_KEEP_RE = 1 builds it; SSB / NFM, AM needs the imaginary parts too): the popped
+// samples' real parts -- written by this lane at the preparation of frame f and read back by the SAME lane at the gain of
+// frame f, two iterations later -- waiting in registers of their owner (a ring of three float4 in the kernel) instead of
+// in the slot, which then holds the chain's operands only: 6 instead of 9 KiB touched per channel, 3 MiB per XCD instead of
+// 4.6 -- VERDICT r04's remedy for the slots' fabric traffic.  Result (interleaved A/B, profiles/r05_ab_keepre.txt): the
+// kernel spills 18 instead of 10 VGPRs (up to 40 in the q15 / general variants), runs 29.2 against 29.0 us per frame, and
+// the fabric traffic falls from 1.306 to 1.288 x only: the slots do not stay in L2 next to 3 GB of streamed samples
+// whatever their size (nontemporal accesses keep their lines in the XCD's L2 too), so a smaller cyclic set buys nothing.
+#ifndef T41RX_PIPE_KEEP_RE
+#define T41RX_PIPE_KEEP_RE 0
+#endif
+template <typename AL, bool NEED_IM, bool KEEP_RE = false>
 // arec: the delay line's magnitudes (computed a frame ago as that frame's newest: carried, not recomputed)
-__device__ __forceinline__ float4 agc_prep_pipe(const cf (&v)[8], float4 agst, float2 &arec, float *lds, float *slot, CoefPtr cf0, int lane) {
+__device__ __forceinline__ float4 agc_prep_pipe(const cf (&v)[8], float4 agst, float2 &arec, float *lds, float *slot, CoefPtr cf0, int lane,
+                                               float4 *re_out = nullptr) {
   constexpr int kAgZ = AL::Z, kAgA = AL::A, kAgG = AL::G;
   wave_sync();
   if (lane < 50) *reinterpret_cast<float4 *>(lds + kAgZ + 4 * lane) = agst;
@@ -871,7 +883,8 @@ __device__ __forceinline__ float4 agc_prep_pipe(const cf (&v)[8], float4 agst, f
     cf z[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) z[k] = *reinterpret_cast<const cf *>(lds + kAgZ + 2 * (3 + 4 * lane + k));
-    *reinterpret_cast<float4 *>(slot + 512 + 4 * lane) = make_float4(z[0].x, z[1].x, z[2].x, z[3].x);
+    if (KEEP_RE) *re_out = make_float4(z[0].x, z[1].x, z[2].x, z[3].x);
+    else *reinterpret_cast<float4 *>(slot + 512 + 4 * lane) = make_float4(z[0].x, z[1].x, z[2].x, z[3].x);
     if (NEED_IM) *reinterpret_cast<float4 *>(slot + 768 + 4 * lane) = make_float4(z[0].y, z[1].y, z[2].y, z[3].y);
   }
   // the delay line for the next frame: the newest 100 inputs, kept in registers (lanes 0..49; the state words are the chain's)
@@ -1200,11 +1213,11 @@ __device__ __forceinline__ void agc_chain_pipe(float *grp, float *stw0, size_t s
 
 // last part of agc_apply: og[k] = popped sample 4 lane + k times the gain from volts
 struct AgcGainIn { float4 vv, zr, zi; };  // requested ahead of the AGC preparation of the front end's frame, which hides the round trip
-template <bool NEED_IM>
-__device__ __forceinline__ AgcGainIn agc_gain_request(const float *slot, int lane) {
+template <bool NEED_IM, bool KEEP_RE = false>
+__device__ __forceinline__ AgcGainIn agc_gain_request(const float *slot, int lane, float4 re_kept = make_float4(0, 0, 0, 0)) {
   AgcGainIn r;
   r.vv = *reinterpret_cast<const float4 *>(slot + 4 * lane);
-  r.zr = *reinterpret_cast<const float4 *>(slot + 512 + 4 * lane);
+  r.zr = KEEP_RE ? re_kept : *reinterpret_cast<const float4 *>(slot + 512 + 4 * lane);
   r.zi = make_float4(0, 0, 0, 0);
   if (NEED_IM) r.zi = *reinterpret_cast<const float4 *>(slot + 768 + 4 * lane);
   return r;

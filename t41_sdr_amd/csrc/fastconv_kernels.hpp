@@ -357,11 +357,12 @@ __global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_kern
           }
           wave_sync();
           float *gO = gOf + 2048 * sg;
+          const LaneOff lof = fresh_off(4 * lane);
 #pragma unroll
           for (int i = 0; i < 8; ++i) {  // float4 F = 64 i + lane: row F >> 3 = the source lane, column lane & 7
             const int row = 8 * i + (lane >> 3);
             const float4 t = lds4(tr + 4 * (8 * row + ((lane & 7) ^ (row & 7))));
-            if (!(T41RX_FCABL & 1) || t.x == 123.456f) stg_stream(gO + 256 * i + 4 * lane, t);
+            if (!(T41RX_FCABL & 1) || t.x == 123.456f) stg_stream(gO + 256 * i, lof, t);
           }
         }
       }
@@ -560,10 +561,11 @@ __global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_fuse
       float4 pI0[2], pI1[2], pQ0[2], pQ1[2];
       auto request = [&](int set, const float *pi, const float *pq) {
         if (T41RX_FF_PF < 2) set = 0;
-        pI0[set] = ldg_stream(pi + 8 * lane);
-        pI1[set] = ldg_stream(pi + 8 * lane + 4);
-        pQ0[set] = ldg_stream(pq + 8 * lane);
-        pQ1[set] = ldg_stream(pq + 8 * lane + 4);
+        const LaneOff lof = fresh_off(8 * lane);
+        pI0[set] = ldg_stream(pi, lof);
+        pI1[set] = ldg_stream(pi, lof, 4);
+        pQ0[set] = ldg_stream(pq, lof);
+        pQ1[set] = ldg_stream(pq, lof, 4);
       };
       float dc_carry = 0.0f;
       if (wv == 0) {
@@ -596,7 +598,7 @@ __global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_fuse
         iq_corr(z);
         {
           const uint64_t P = phase0 - (uint64_t)(511 - 8 * lane) * dphi;
-          mix(z, P, tab[kTabSinCos + (int)(P >> 56)]);
+          mix(z, P, ldg2(tab + kTabSinCos, (unsigned)(P >> 56)));
         }
         wave_sync();
         float *xw = lds + kX + 20 * lane;
@@ -625,10 +627,18 @@ __global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_fuse
           dc2 = f2{(g_rf_i != g_rf) ? -dc_carry : dc_carry, dc_highpass_end_state<4>(x, hp4.x, hp4.y)};
         }
         float2 osc_tab[4];
+        uint64_t osc_p[4];  // (rx512_kernel.hpp: unsigned sample numbers, the sub-block's part of the phase scalar)
+        {
+          const uint64_t Pl = (uint64_t)(unsigned)(8 * lane + 1) * dphi;
 #pragma unroll
-        for (int sb = 0; sb < 4; ++sb) {
-          const uint64_t P = phase0 + (uint64_t)(512 * sb + 8 * lane + 1) * dphi;
-          osc_tab[sb] = tab[kTabSinCos + (int)(P >> 56)];
+          for (int sb = 0; sb < 4; ++sb) {
+#if T41RX_PHASE_SPLIT
+            osc_p[sb] = (phase0 + (uint64_t)(512 * sb) * dphi) + Pl;
+#else
+            osc_p[sb] = phase0 + (uint64_t)(512 * sb + 8 * lane + 1) * dphi;
+#endif
+            osc_tab[sb] = ldg2(tab + kTabSinCos, (unsigned)(osc_p[sb] >> 56));
+          }
         }
 #pragma unroll
         for (int rd = 0; rd < 2; ++rd) {
@@ -668,7 +678,11 @@ __global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_fuse
 #pragma unroll
               for (int k = 0; k < 8; ++k) z[k] *= splat(amp[k]);
             }
+#if T41RX_PHASE_SPLIT
+            mix(z, osc_p[sb], osc_tab[sb]);
+#else
             mix(z, phase0 + (uint64_t)(n0 + 1) * dphi, osc_tab[sb]);
+#endif
             wave_sync();
             float *xw = lds + kX + 20 * lane;
 #pragma unroll
@@ -902,11 +916,12 @@ __global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_fuse
         }
         wave_sync();
         float *gO = gOf + 2048 * sg;
+        const LaneOff lof = fresh_off(4 * lane);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const int row = 8 * i + (lane >> 3);
           const float4 t = lds4(tr + 4 * (8 * row + ((lane & 7) ^ (row & 7))));
-          stg_stream(gO + 256 * i + 4 * lane, t);
+          stg_stream(gO + 256 * i, lof, t);
         }
       }
       if (threadIdx.x < 8) yt_reg = YT[8 * R + threadIdx.x];

@@ -326,13 +326,15 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
       const bool preroll = SEGPAR && first_iter && f > 0;  // this wave rebuilds its filter memories from the preceding input
       if (preroll) {  // requested first, into register set 1 (sub-block 1 is requested once the pre-roll is done)
         if (!WQ15) {
-          pI0[1] = ldg_stream(gI - 512 + 8 * lane);
-          pI1[1] = ldg_stream(gI - 512 + 8 * lane + 4);
-          pQ0[1] = ldg_stream(gQ - 512 + 8 * lane);
-          pQ1[1] = ldg_stream(gQ - 512 + 8 * lane + 4);
+          const LaneOff lof = fresh_off(8 * lane);
+          pI0[1] = ldg_stream(gI - 512, lof);
+          pI1[1] = ldg_stream(gI - 512, lof, 4);
+          pQ0[1] = ldg_stream(gQ - 512, lof);
+          pQ1[1] = ldg_stream(gQ - 512, lof, 4);
         } else {
-          pI0[1] = ldg_stream(gI - 256 + 4 * lane);
-          pQ0[1] = ldg_stream(gQ - 256 + 4 * lane);
+          const LaneOff lof = fresh_off(4 * lane);
+          pI0[1] = ldg_stream(gI - 256, lof);
+          pQ0[1] = ldg_stream(gQ - 256, lof);
         }
       }
       float4 tailI;
@@ -340,16 +342,18 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
         tailI = WQ15 ? make_float4(q15_lo(tailNq.x), q15_hi(tailNq.x), q15_lo(tailNq.y), q15_hi(tailNq.y)) : tailN;
       } else if (!WQ15) {
         if (!carried) {
-          pI0[0] = ldg_stream(gI + 8 * lane);
-          pI1[0] = ldg_stream(gI + 8 * lane + 4);
-          pQ0[0] = ldg_stream(gQ + 8 * lane);
-          pQ1[0] = ldg_stream(gQ + 8 * lane + 4);
+          const LaneOff lof = fresh_off(8 * lane);
+          pI0[0] = ldg_stream(gI, lof);
+          pI1[0] = ldg_stream(gI, lof, 4);
+          pQ0[0] = ldg_stream(gQ, lof);
+          pQ1[0] = ldg_stream(gQ, lof, 4);
         }
-        tailI = *reinterpret_cast<const float4 *>(gI + (L - 256) + 4 * lane);
+        tailI = ldg4(gI + (L - 256), fresh_off(4 * lane));
       } else {  // 8 samples = 16 bytes per lane and array
         if (!carried) {
-          pI0[0] = ldg_stream(gI + 4 * lane);
-          pQ0[0] = ldg_stream(gQ + 4 * lane);
+          const LaneOff lof = fresh_off(4 * lane);
+          pI0[0] = ldg_stream(gI, lof);
+          pQ0[0] = ldg_stream(gQ, lof);
         }
         const float2 t = *reinterpret_cast<const float2 *>(gI + (L - 256) / 2 + 2 * lane);
         tailI = make_float4(q15_lo(t.x), q15_hi(t.x), q15_lo(t.y), q15_hi(t.y));
@@ -393,14 +397,16 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
         // (register set 1 still holds the pre-roll)
       } else if (!WQ15) {
         if (!carried1) {
-          pI0[1] = ldg_stream(gI + 512 + 8 * lane);
-          pI1[1] = ldg_stream(gI + 512 + 8 * lane + 4);
-          pQ0[1] = ldg_stream(gQ + 512 + 8 * lane);
-          pQ1[1] = ldg_stream(gQ + 512 + 8 * lane + 4);
+          const LaneOff lof = fresh_off(8 * lane);
+          pI0[1] = ldg_stream(gI + 512, lof);
+          pI1[1] = ldg_stream(gI + 512, lof, 4);
+          pQ0[1] = ldg_stream(gQ + 512, lof);
+          pQ1[1] = ldg_stream(gQ + 512, lof, 4);
         }
       } else if (!carried1) {
-        pI0[1] = ldg_stream(gI + 256 + 4 * lane);
-        pQ0[1] = ldg_stream(gQ + 256 + 4 * lane);
+        const LaneOff lof = fresh_off(4 * lane);
+        pI0[1] = ldg_stream(gI + 256, lof);
+        pQ0[1] = ldg_stream(gQ + 256, lof);
       }
 
       // ---- delay lines -> LDS (first frame of a launch / every segment-0; afterwards they are
@@ -494,13 +500,15 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
         const float4 rI0 = pI0[1], rI1 = WQ15 ? pI0[1] : pI1[1], rQ0 = pQ0[1], rQ1 = WQ15 ? pQ0[1] : pQ1[1];
         // now that set 1 is consumed: this segment's sub-block 1
         if (!WQ15) {
-          pI0[1] = ldg_stream(gI + 512 + 8 * lane);
-          pI1[1] = ldg_stream(gI + 512 + 8 * lane + 4);
-          pQ0[1] = ldg_stream(gQ + 512 + 8 * lane);
-          pQ1[1] = ldg_stream(gQ + 512 + 8 * lane + 4);
+          const LaneOff lof = fresh_off(8 * lane);
+          pI0[1] = ldg_stream(gI + 512, lof);
+          pI1[1] = ldg_stream(gI + 512, lof, 4);
+          pQ0[1] = ldg_stream(gQ + 512, lof);
+          pQ1[1] = ldg_stream(gQ + 512, lof, 4);
         } else {
-          pI0[1] = ldg_stream(gI + 256 + 4 * lane);
-          pQ0[1] = ldg_stream(gQ + 256 + 4 * lane);
+          const LaneOff lof = fresh_off(4 * lane);
+          pI0[1] = ldg_stream(gI + 256, lof);
+          pQ0[1] = ldg_stream(gQ + 256, lof);
         }
         dc_pre = rebuild_from(rI0, rI1, rQ0, rQ1, phase0);
         // a frame's first segment: the shared biquad comes from the previous frame's Q (Process.cpp:127-128)
@@ -518,7 +526,7 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
         float4 tailF = tailI;
         if (PART != 0) {  // the frame's last 256 I samples are seg segments further on
           if (!WQ15) {
-            tailF = *reinterpret_cast<const float4 *>(gI + (seg * L - 256) + 4 * lane);
+            tailF = ldg4(gI + (seg * L - 256), fresh_off(4 * lane));
           } else {
             const float2 t = *reinterpret_cast<const float2 *>(gI + (seg * L - 256) / 2 + 2 * lane);
             tailF = make_float4(q15_lo(t.x), q15_hi(t.x), q15_lo(t.y), q15_hi(t.y));
@@ -537,11 +545,24 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
       // are requested HERE and nowhere later: vector-memory results return in issue order, so a
       // table read issued between two input requests could only be used once every older input
       // request has landed -- it would cut the two-sub-block prefetch distance to nothing.
+      // (the sample number is widened UNSIGNED -- as an int it is sign-extended, lane's range being unknown behind
+      // FRESH_LANE, and the 64-bit product costs two more VALU instructions -- and only the lane's part is a vector
+      // product: the sub-block's part is the same for every lane, scalar arithmetic.  Bits 24..55 of each phase are
+      // kept for the sub-block that needs them instead of being worked out again there.)
       float2 osc_tab[4];
+      uint32_t osc_u[4];
+      {
+        const uint64_t Pl = (uint64_t)(unsigned)(8 * lane + 1) * dphi;
   #pragma unroll
-      for (int sb = 0; sb < 4; ++sb) {
-        const uint64_t P = phase0 + (uint64_t)(512 * sb + 8 * lane + 1) * dphi;
-        osc_tab[sb] = (PART == 1) ? reinterpret_cast<const float2 *>(smem)[(int)(P >> 56)] : tab[kTabSinCos + (int)(P >> 56)];
+        for (int sb = 0; sb < 4; ++sb) {
+  #if T41RX_PHASE_SPLIT
+          const uint64_t P = (phase0 + (uint64_t)(512 * sb) * dphi) + Pl;
+  #else
+          const uint64_t P = phase0 + (uint64_t)(512 * sb + 8 * lane + 1) * dphi;
+  #endif
+          osc_u[sb] = (uint32_t)(P >> 24);
+          osc_tab[sb] = (PART == 1) ? reinterpret_cast<const float2 *>(smem)[(int)(P >> 56)] : ldg2(tab + kTabSinCos, (unsigned)(P >> 56));
+        }
       }
 
   #pragma unroll
@@ -570,15 +591,17 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
           }
           if (s < 2) {  // refill this register set with the sub-block after next
             if (!WQ15) {
-              const int o = 512 * (s + 2) + 8 * lane;
-              pI0[h] = ldg_stream(gI + o);
-              pI1[h] = ldg_stream(gI + o + 4);
-              pQ0[h] = ldg_stream(gQ + o);
-              pQ1[h] = ldg_stream(gQ + o + 4);
+              const int o = 512 * (s + 2);
+              const LaneOff lof = fresh_off(8 * lane);
+              pI0[h] = ldg_stream(gI + o, lof);
+              pI1[h] = ldg_stream(gI + o, lof, 4);
+              pQ0[h] = ldg_stream(gQ + o, lof);
+              pQ1[h] = ldg_stream(gQ + o, lof, 4);
             } else {
-              const int o = 256 * (s + 2) + 4 * lane;
-              pI0[h] = ldg_stream(gI + o);
-              pQ0[h] = ldg_stream(gQ + o);
+              const int o = 256 * (s + 2);
+              const LaneOff lof = fresh_off(4 * lane);
+              pI0[h] = ldg_stream(gI + o, lof);
+              pQ0[h] = ldg_stream(gQ + o, lof);
             }
           } else if (PART == 1 || (KEEP && kPF >= 1)) {  // the next segment's / frame's sub-blocks 0 and 1
             // Requested UNCONDITIONALLY (behind the launch's last frame: from the constant table, 8 KiB of L2-resident
@@ -592,7 +615,7 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
               const float *nQ = more ? gQ + fstep : reinterpret_cast<const float *>(tab);
               if (KEEP && s == 3) {  // and the I tail that decides the next frame's Q start state
                 if (!WQ15) {
-                  tailN = *reinterpret_cast<const float4 *>(nI + (L - 256) + 4 * lane);
+                  tailN = ldg4(nI + (L - 256), fresh_off(4 * lane));
                 } else {  // (raw q15 words; converted when used, not here: that would wait for them)
                   tailNq = *reinterpret_cast<const float2 *>(nI + (L - 256) / 2 + 2 * lane);
                 }
@@ -600,15 +623,17 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
               if (KEEP && kPF < 2 && s == 3) {
                 // sub-block 1 is requested at the top of the next frame
               } else if (!WQ15) {
-                const int o = 512 * (s - 2) + 8 * lane;
-                pI0[h] = ldg_stream(nI + o);
-                pI1[h] = ldg_stream(nI + o + 4);
-                pQ0[h] = ldg_stream(nQ + o);
-                pQ1[h] = ldg_stream(nQ + o + 4);
+                const int o = 512 * (s - 2);
+                const LaneOff lof = fresh_off(8 * lane);
+                pI0[h] = ldg_stream(nI + o, lof);
+                pI1[h] = ldg_stream(nI + o, lof, 4);
+                pQ0[h] = ldg_stream(nQ + o, lof);
+                pQ1[h] = ldg_stream(nQ + o, lof, 4);
               } else {
-                const int o = 256 * (s - 2) + 4 * lane;
-                pI0[h] = ldg_stream(nI + o);
-                pQ0[h] = ldg_stream(nQ + o);
+                const int o = 256 * (s - 2);
+                const LaneOff lof = fresh_off(4 * lane);
+                pI0[h] = ldg_stream(nI + o, lof);
+                pQ0[h] = ldg_stream(nQ + o, lof);
               }
             }
           } else if (s == 3 && !KEEP) {  // last sub-block: prefetch the overlap-save "previous" block instead
@@ -670,8 +695,12 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
           // top of the frame, see there) x 32-bit Taylor remainder
           cf base;
           {
+  #if T41RX_PHASE_SPLIT
+            const uint32_t u = osc_u[s];
+  #else
             const uint64_t P = phase0 + (uint64_t)(n0 + 1) * dphi;
             const uint32_t u = (uint32_t)(P >> 24);
+  #endif
             const float ang = (float)u * (float)(6.283185307179586476925 / 256.0 / 4294967296.0);
             const float a2 = ang * ang;
             const float sn = ang * fmaf(a2, -1.0f / 6.0f, 1.0f);
@@ -782,13 +811,15 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
         const size_t last = (size_t)(a.nframes - 1 - f) * L;  // the call's last segment, relative to this one
         float4 rI0, rI1, rQ0, rQ1;
         if (!WQ15) {
-          rI0 = ldg_stream(gI + last + 1536 + 8 * lane);
-          rI1 = ldg_stream(gI + last + 1536 + 8 * lane + 4);
-          rQ0 = ldg_stream(gQ + last + 1536 + 8 * lane);
-          rQ1 = ldg_stream(gQ + last + 1536 + 8 * lane + 4);
+          const LaneOff lof = fresh_off(8 * lane);
+          rI0 = ldg_stream(gI + last + 1536, lof);
+          rI1 = ldg_stream(gI + last + 1536, lof, 4);
+          rQ0 = ldg_stream(gQ + last + 1536, lof);
+          rQ1 = ldg_stream(gQ + last + 1536, lof, 4);
         } else {
-          rI0 = rI1 = ldg_stream(gI + last / 2 + 768 + 4 * lane);
-          rQ0 = rQ1 = ldg_stream(gQ + last / 2 + 768 + 4 * lane);
+          const LaneOff lof = fresh_off(4 * lane);
+          rI0 = rI1 = ldg_stream(gI + last / 2 + 768, lof);
+          rQ0 = rQ1 = ldg_stream(gQ + last / 2 + 768, lof);
         }
         phase0 += (uint64_t)(a.nframes - 1 - f) * (uint64_t)L * dphi;  // the oscillator phase after the call
         const f2 dc_end = rebuild_from(rI0, rI1, rQ0, rQ1, phase0);
@@ -1583,7 +1614,7 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
             for (int i = 0; i < 4; ++i) {  // float4 F = 64 i + lane of this half: row F >> 2, column F & 3
               const int row = 16 * i + (lane >> 2);
               const float4 t = lds4(tr + 4 * (4 * row + ((lane & 3) ^ ((row >> 1) & 3))));
-              stg_stream(gO + 32 * row + 16 * (u >> 2) + 4 * (lane & 3), t);
+              stg_stream(gO + 16 * (u >> 2), fresh_off(32 * row + 4 * (lane & 3)), t);
             }
             wave_sync();
           }
@@ -1602,18 +1633,20 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
       // ... and every global store instruction then writes 1 KiB of consecutive addresses:
       // float4 index F = 64 i + lane lives in row F >> 3 = 8 i + (lane >> 3), column lane & 7
       if (!WQ15 && !HALFTR) {
+        const LaneOff lof = fresh_off(4 * lane);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const int row = 8 * i + (lane >> 3);
           const float4 t = lds4(tr + 4 * (8 * row + ((lane & 7) ^ (row & 7))));
-          stg_stream(gO + 256 * i + 4 * lane, t);
+          stg_stream(gO + 256 * i, lof, t);
         }
       } else if (WQ15) {  // 4 pieces per row: piece F = 64 i + lane is row F >> 2, column lane & 3
+        const LaneOff lof = fresh_off(4 * lane);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int row = 16 * i + (lane >> 2);
           const float4 t = lds4(tr + 4 * (4 * row + ((lane & 3) ^ ((row >> 1) & 3))));
-          stg_stream(gO + 256 * i + 4 * lane, t);
+          stg_stream(gO + 256 * i, lof, t);
         }
       }
       if (PARK) {  // the resident state returns to its place

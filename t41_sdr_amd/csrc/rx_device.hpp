@@ -385,6 +385,91 @@ __device__ __forceinline__ float4 ldg_stream(const float *p) {
 __device__ __forceinline__ void stg_stream(float *p, float4 v) {
   __builtin_nontemporal_store(f4n{v.x, v.y, v.z, v.w}, reinterpret_cast<f4n *>(p));
 }
+// the same at (wave-uniform base) + (per-lane offset): the request takes its address as `v_off, s[base:base+1] offset:imm`
+// instead of a 64-bit VGPR pair somebody has to compute (round 5: 13 v_ashrrev_i32 + 22 v_lshl_add_u64 + 5 v_lshlrev_b64
+// + 14 v_add(c)_co_u32 per SSB frame).  Three things are needed for the selector to see `sgpr + zext(vgpr32)`:
+// the offset widened UNSIGNED (`base + int` sign-extends: lane went through FRESH_LANE, its range is unknown); the
+// widening in the request's own basic block (hence fresh_off(): a widened offset is hoisted and shared otherwise, and the
+// selector, which works block by block, then sees a 64-bit register, not a zext); and the base an opaque scalar, or
+// neighbouring requests' addresses are merged into one 64-bit VGPR sum + immediates again.
+// T41RX_SADDR=0: the previous address form (A/B builds).
+#ifndef T41RX_SADDR
+#define T41RX_SADDR 1
+#endif
+// T41RX_PHASE_SPLIT=0: the oscillator phases of a frame as round 4 worked them out (A/B builds)
+#ifndef T41RX_PHASE_SPLIT
+#define T41RX_PHASE_SPLIT 1
+#endif
+#ifndef T41RX_SADDR_BASE
+#define T41RX_SADDR_BASE 1
+#endif
+struct LaneOff {
+  unsigned bytes;
+};
+__device__ __forceinline__ LaneOff fresh_off(int floats) {  // one per group of requests that share the lane offset
+  unsigned o = (unsigned)floats * 4u;
+#if T41RX_SADDR
+  asm volatile("" : "+v"(o));
+#endif
+  return LaneOff{o};
+}
+typedef __attribute__((address_space(1))) char *GlobalBytes;
+typedef const __attribute__((address_space(1))) char *CGlobalBytes;
+typedef const __attribute__((address_space(1))) f4n *CGlobalF4;
+typedef __attribute__((address_space(1))) f4n *GlobalF4;
+__device__ __forceinline__ CGlobalBytes global_at(const float *ubase, LaneOff o) {
+  CGlobalBytes b = (CGlobalBytes)(ubase);
+#if T41RX_SADDR_BASE
+  asm("" : "+s"(b));
+#endif
+  return b + o.bytes;
+}
+__device__ __forceinline__ GlobalBytes global_at(float *ubase, LaneOff o) {
+  GlobalBytes b = (GlobalBytes)(ubase);
+#if T41RX_SADDR_BASE
+  asm("" : "+s"(b));
+#endif
+  return b + o.bytes;
+}
+// (imm: a compile-time number of floats on top, for the request's immediate-offset field: up to 1023)
+__device__ __forceinline__ float4 ldg_stream(const float *ubase, LaneOff o, int imm = 0) {
+#if T41RX_SADDR
+  const f4n t = __builtin_nontemporal_load((CGlobalF4)(global_at(ubase, o) + 4 * imm));
+  return make_float4(t.x, t.y, t.z, t.w);
+#else
+  return ldg_stream(reinterpret_cast<const float *>(reinterpret_cast<const char *>(ubase) + (int)o.bytes) + imm);
+#endif
+}
+__device__ __forceinline__ void stg_stream(float *ubase, LaneOff o, float4 v) {
+#if T41RX_SADDR
+  __builtin_nontemporal_store(f4n{v.x, v.y, v.z, v.w}, (GlobalF4)global_at(ubase, o));
+#else
+  stg_stream(reinterpret_cast<float *>(reinterpret_cast<char *>(ubase) + (int)o.bytes), v);
+#endif
+}
+__device__ __forceinline__ float2 ldg2(const float2 *ubase, unsigned idx) {  // ubase[idx] of a wave-uniform table
+#if T41RX_SADDR
+  typedef float f2n __attribute__((ext_vector_type(2)));
+  CGlobalBytes b = (CGlobalBytes)(ubase);
+#if T41RX_SADDR_BASE
+  asm("" : "+s"(b));
+#endif
+  unsigned o = idx * 8u;
+  asm volatile("" : "+v"(o));  // (or zext(trunc(P >> 56) * 8) becomes a 64-bit and(P >> 53, 0x7f8): no zext left to select)
+  const f2n t = *(const __attribute__((address_space(1))) f2n *)(b + o);
+  return make_float2(t.x, t.y);
+#else
+  return ubase[(int)idx];
+#endif
+}
+__device__ __forceinline__ float4 ldg4(const float *ubase, LaneOff o) {  // (ordinary, cached load)
+#if T41RX_SADDR
+  const f4n t = *(CGlobalF4)global_at(ubase, o);
+  return make_float4(t.x, t.y, t.z, t.w);
+#else
+  return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(ubase) + (int)o.bytes);
+#endif
+}
 
 // the two q15 samples packed in one 32-bit word, as floats (exact)
 __device__ __forceinline__ float q15_lo(float w) { return (float)(short)(__float_as_uint(w) & 0xffffu); }

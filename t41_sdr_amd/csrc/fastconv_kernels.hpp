@@ -113,10 +113,14 @@ __global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_kern
   // (pass 2 wants the 28 registers they would hold)
   cf twp[H][R > 1 ? R - 1 : 1];
   auto load_twp = [&]() {
+    // (two scalar bases, one per h, and R - 1 lane offsets shared by both: a base per entry runs the kernel out of SGPRs)
+    const LaneOff lo = fresh_off(2 * lane);
 #pragma unroll
-    for (int h = 0; h < H; ++h)
+    for (int q = 1; q < R; ++q) {
+      const LaneOff oq = LaneOff{lo.bytes + 4096u * (q - 1)};
 #pragma unroll
-      for (int q = 1; q < R; ++q) twp[h][q - 1] = twN[512 * (q - 1) + lane + 64 * (wv + NWV * h)];
+      for (int h = 0; h < H; ++h) twp[h][q - 1] = ldg_cf(twN + 64 * (wv + NWV * h), oq);
+    }
   };
 
 #ifdef T41RX_STAMP
@@ -186,12 +190,13 @@ __global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_kern
     // the filter mask of this wave's rows of pass 2 (q = wv, wv + 4): requested here, so its L2
     // round trip runs under the barrier and the forward FFTs
     cf mk[H][8];
+    const LaneOff lom = fresh_off(2 * lane);
 #pragma unroll
     for (int h = 0; h < H; ++h) {
       const int q = wv + NWV * h;
       if (q < R) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) mk[h][r] = maskN[512 * q + lane + 64 * r];
+        for (int r = 0; r < 8; ++r) mk[h][r] = ldg_cf(maskN + 512 * q, lom, 64 * r);
       }
     }
     STAMP(5);
@@ -495,10 +500,14 @@ __global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_fuse
   }
   cf twp[H][R - 1];
   auto load_twp = [&]() {
+    // (two scalar bases, one per h, and R - 1 lane offsets shared by both: a base per entry runs the kernel out of SGPRs)
+    const LaneOff lo = fresh_off(2 * lane);
 #pragma unroll
-    for (int h = 0; h < H; ++h)
+    for (int q = 1; q < R; ++q) {
+      const LaneOff oq = LaneOff{lo.bytes + 4096u * (q - 1)};
 #pragma unroll
-      for (int q = 1; q < R; ++q) twp[h][q - 1] = twN[512 * (q - 1) + lane + 64 * (wv + NWV * h)];
+      for (int h = 0; h < H; ++h) twp[h][q - 1] = ldg_cf(twN + 64 * (wv + NWV * h), oq);
+    }
   };
   const float *gIc = a.I + (size_t)ch * a.nframes * L;  // (a.nframes counts 2048-sample segments)
   const float *gQc = a.Q + (size_t)ch * a.nframes * L;
@@ -575,9 +584,10 @@ __global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_fuse
         // its stores were drained before the barrier above, and these loads do not look at this CU's L1)
         const float *src = (f == 0) ? st : a.mid + ((size_t)ch * 2 + ((f - 1) & 1)) * 256;
         request(0, gI, gQ);
-        float4 h1 = make_float4(0, 0, 0, 0), h2 = make_float4(0, 0, 0, 0);
-        if (lane < 14) h1 = ldg_stream(src + kStDec1 + 4 * lane);
-        if (lane < 24) h2 = ldg_stream(src + kStDec2 + 4 * lane);
+        float4 h1 = any_float4(), h2 = any_float4();
+        const LaneOff lo4 = fresh_off(4 * lane);
+        if (lane < 14) h1 = ldg_stream(src + kStDec1, lo4);
+        if (lane < 24) h2 = ldg_stream(src + kStDec2, lo4);
         const float4 dcs = ldg_stream(src + kStMisc);  // (kMiscDc first)
         if (T41RX_FF_PF >= 2) request(1, gI + 512, gQ + 512);
         wave_sync();
@@ -622,7 +632,7 @@ __global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_fuse
         if (wv == 0 && sg == 0) {
           // Q's DC-block start state = the state after ALL of the frame's I (one shared instance runs over I then Q,
           // Process.cpp:127-128): a1^256 ~ 3e-18, so the frame's last 256 I samples decide it
-          const float4 tailF = *reinterpret_cast<const float4 *>(gI + (R * L - 256) + 4 * lane);
+          const float4 tailF = ldg4(gI + (R * L - 256), fresh_off(4 * lane));
           const float x[4] = {tailF.x * g_rf, tailF.y * g_rf, tailF.z * g_rf, tailF.w * g_rf};
           dc2 = f2{(g_rf_i != g_rf) ? -dc_carry : dc_carry, dc_highpass_end_state<4>(x, hp4.x, hp4.y)};
         }
@@ -772,11 +782,12 @@ __global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_fuse
       }
     }
     cf mk[H][8];
+    const LaneOff lom = fresh_off(2 * lane);
 #pragma unroll
     for (int h = 0; h < H; ++h) {
       const int q = wv + NWV * h;
 #pragma unroll
-      for (int r = 0; r < 8; ++r) mk[h][r] = maskN[512 * q + lane + 64 * r];
+      for (int r = 0; r < 8; ++r) mk[h][r] = ldg_cf(maskN + 512 * q, lom, 64 * r);
     }
     __syncthreads();
     FRESH_LANE(); FRESH_WV(wv);

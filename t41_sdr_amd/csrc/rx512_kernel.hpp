@@ -358,8 +358,10 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
         const float2 t = *reinterpret_cast<const float2 *>(gI + (L - 256) / 2 + 2 * lane);
         tailI = make_float4(q15_lo(t.x), q15_hi(t.x), q15_lo(t.y), q15_hi(t.y));
       }
-      float4 h1 = make_float4(0, 0, 0, 0), h2 = make_float4(0, 0, 0, 0);
-      float4 ovl0 = make_float4(0, 0, 0, 0), ovl1 = ovl0, ovl2 = ovl0;  // KEEP, first frame: overlap block, x2 history
+      // (loaded and, behind the table staging, stored under the same conditions: no start values needed -- as zeros they
+      // are written on every frame, 20 v_mov_b32 hoisted above the branch)
+      float4 h1 = any_float4(), h2 = any_float4();
+      float4 ovl0 = any_float4(), ovl1 = any_float4(), ovl2 = any_float4();  // KEEP, first frame: overlap block, x2 history
       if (!hist_carried && !preroll) {
         if (lane < 14) h1 = *reinterpret_cast<const float4 *>(st + kStDec1 + 4 * lane);
         if (lane < 24) h2 = *reinterpret_cast<const float4 *>(st + kStDec2 + 4 * lane);
@@ -487,7 +489,7 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
         auto pidx = [](int o) { return xpad(o); };
         fir_pair<kDec1Taps, 1, 5, 18, 6>(xw, pidx, cf0, kCoDec1, o1[0], o1[1]);
         // its first outputs saw no history and are dropped; the last 48 (lanes 40..63) are the /2 history
-        float4 hh = make_float4(0, 0, 0, 0);
+        float4 hh = any_float4();
         if (lane < 14) hh = lds4(lds + kX + 2 * xpad(512 + 2 * lane));
         wave_sync();
         if (lane < 14) *reinterpret_cast<float4 *>(lds + kX + 2 * xpad(2 * lane)) = hh;
@@ -754,7 +756,7 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
           STAMP(3);  // LDS staging + /4 decimator
         // -- roll the /4 history (logical 512..539 -> 0..27) and append the /4 outputs
           {
-            float4 hh = make_float4(0, 0, 0, 0);
+            float4 hh = any_float4();
             if (lane < 14) hh = lds4(lds + kX + 2 * xpad(512 + 2 * lane));
             wave_sync();
             if (lane < 14) *reinterpret_cast<float4 *>(lds + kX + 2 * xpad(2 * lane)) = hh;
@@ -788,7 +790,7 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
         }
         STAMP(5);  // /2 decimator
       {  // roll the /2 history: logical 256..303 -> 0..47
-          float4 hh = make_float4(0, 0, 0, 0);
+          float4 hh = any_float4();
           if (lane < 24) hh = lds4(lds + kY1 + y1slot(128 + lane));
           wave_sync();
           if (lane < 24) *reinterpret_cast<float4 *>(lds + kY1 + y1slot(lane)) = hh;
@@ -1503,6 +1505,10 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
         w[4 * i + 2] = t.z;
         w[4 * i + 3] = t.w;
       }
+      // (w[0] is padding nobody reads; told so, hipcc narrows the seven 16-byte reads to the 27 floats behind it:
+      // 13 ds_read2_b32 + 1 ds_read_b32 at 4-byte alignment, each with a VALU add for an address that no longer fits
+      // the offset field.  Kept alive, the reads stay ds_read_b128 at immediate offsets.)
+      asm volatile("" ::"v"(w[0]));
       if (KEEP) {  // next frame's history: to its LDS slot
         if (lane < 6) *reinterpret_cast<float4 *>(lds + G::kH1 + 4 * lane) = lds4(lds + kI1 + 256 + 4 * lane);
       } else if (lane < 6) {
@@ -1581,7 +1587,7 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
       constexpr bool PARK = KEEP && !WQ15 && !T41RX_X_HALFTR;
       constexpr int kOvPark = (2048 - G::kOV + 3) / 4;  // float4s of the overlap block below float 2048
       static_assert(!PARK || (kOvPark > 0 && kOvPark <= 64 && G::kH1 >= 2048), "parking layout");
-      float4 park_h = make_float4(0, 0, 0, 0), park_o = make_float4(0, 0, 0, 0);
+      float4 park_h = any_float4(), park_o = any_float4();
       if (PARK) {
         if (lane < 14) park_h = lds4(lds + kX + 2 * xpad(2 * lane));
         else if (lane >= 16 && lane < 40) park_h = lds4(lds + kY1 + y1slot(lane - 16));

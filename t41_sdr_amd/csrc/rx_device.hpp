@@ -53,6 +53,11 @@
 #include "rx_kernels.hpp"
 #include "wave_fft.hpp"
 
+// T41RX_SCAN_DPP=0: the DC high-pass scan's steps inside the rows as moves + packed multiply-adds (A/B builds)
+#ifndef T41RX_SCAN_DPP
+#define T41RX_SCAN_DPP 1
+#endif
+
 namespace t41 {
 
 // ------------------------------------------------------------------------------------------
@@ -264,10 +269,29 @@ struct HpTab {
 template <int n>
 __device__ __forceinline__ f2 hp_scan(f2 B, float m15, float m31) {
   constexpr HpTab<n> T{};
+#if T41RX_SCAN_DPP
+  // (round 5: the four steps inside the rows the same way -- two v_fmac_f32_dpp instead of two v_mov_b32_dpp and a
+  // packed multiply-add; the same fused operations on the same operands, so the same bits)
+  {
+    float sx = B.x, sy = B.y;
+    asm("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %1, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 0\n\tv_fmac_f32_dpp %0, %0, %3 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %1, %1, %3 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 0\n\tv_fmac_f32_dpp %0, %0, %4 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %1, %1, %4 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 0\n\tv_fmac_f32_dpp %0, %0, %5 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %1, %1, %5 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "+v"(sx), "+v"(sy)
+        : "v"(T.scanA[0]), "v"(T.scanA[1]), "v"(T.scanA[2]), "v"(T.scanA[3]));
+    B = f2{sx, sy};
+  }
+#else
   B = pk_fma(splat(T.scanA[0]), dpp_f2<kDppRowShr1, 0xf, true>(B), B);
   B = pk_fma(splat(T.scanA[1]), dpp_f2<kDppRowShr2, 0xf, true>(B), B);
   B = pk_fma(splat(T.scanA[2]), dpp_f2<kDppRowShr4, 0xf, true>(B), B);
   B = pk_fma(splat(T.scanA[3]), dpp_f2<kDppRowShr8, 0xf, true>(B), B);
+#endif
   // the two row-stitching steps as v_fmac_f32 with the DPP operand built in (VOP2; the packed
   // form needs the shuffled value in a register first, zeroed for the rows the step leaves alone):
   // rows outside row_mask are simply not written
@@ -375,6 +399,25 @@ __device__ __forceinline__ CoefPtr fresh_coef(CoefPtr p) {
 }
 
 __device__ __forceinline__ float4 lds4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+// "whatever is in the registers": the start value of a float4 that some lanes load under a condition and the same lanes
+// use under the same condition behind a wave_sync().  With zeros as the start value the compiler has to write them (it
+// cannot see through the fence that the other lanes' values are never read): 33 v_mov_b32 v, 0 per SSB frame, round 5.
+// T41RX_ZERO_INIT=1: zeros (A/B builds).
+#ifndef T41RX_ZERO_INIT
+#define T41RX_ZERO_INIT 0
+#endif
+__device__ __forceinline__ float4 any_float4() {
+#if T41RX_ZERO_INIT
+  return make_float4(0, 0, 0, 0);
+#else
+  // (an undefined value on purpose; __builtin_nondeterministic_value() would do, but a frozen undef is lowered to 0)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wuninitialized"
+  float4 t;
+  return t;
+#pragma clang diagnostic pop
+#endif
+}
 // streaming (read-once / write-once) global accesses: nontemporal, so they do not evict the
 // per-channel state and the constant tables from L2 / Infinity Cache
 typedef float f4n __attribute__((ext_vector_type(4)));
@@ -461,6 +504,16 @@ __device__ __forceinline__ float2 ldg2(const float2 *ubase, unsigned idx) {  // 
 #else
   return ubase[(int)idx];
 #endif
+}
+// the 8-byte entry at ubase + o (+ imm entries: compile-time, for the offset field, up to 511) of a wave-uniform table
+__device__ __forceinline__ f2 ldg_cf(const f2 *ubase, LaneOff o, int imm = 0) {
+  typedef float f2n __attribute__((ext_vector_type(2)));
+#if T41RX_SADDR
+  const f2n t = *(const __attribute__((address_space(1))) f2n *)(global_at(reinterpret_cast<const float *>(ubase), o) + 8 * imm);
+#else
+  const f2n t = *reinterpret_cast<const f2n *>(reinterpret_cast<const char *>(ubase) + (int)o.bytes + 8 * imm);
+#endif
+  return f2{t.x, t.y};
 }
 __device__ __forceinline__ float4 ldg4(const float *ubase, LaneOff o) {  // (ordinary, cached load)
 #if T41RX_SADDR

@@ -304,6 +304,7 @@ __global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_kern
             w[4 * i + 2] = t.z;
             w[4 * i + 3] = t.w;
           }
+          asm volatile("" ::"v"(w[0]));  // (rx512_kernel.hpp: or the 16-byte reads are narrowed to ds_read2_b32 + address adds)
 #pragma unroll
           for (int u = 0; u < 4; ++u) u1[h][u] = splat(0.0f);
 #pragma unroll
@@ -619,7 +620,7 @@ __global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_fuse
         cf o1[2];
         auto pidx = [](int o) { return xpad(o); };
         fir_pair<kDec1Taps, 1, 5, 18, 6>(xw, pidx, cf0, kCoDec1, o1[0], o1[1]);
-        float4 hh = make_float4(0, 0, 0, 0);
+        float4 hh = any_float4();
         if (lane < 14) hh = lds4(lds + kX + 2 * xpad(512 + 2 * lane));
         wave_sync();
         if (lane < 14) *reinterpret_cast<float4 *>(lds + kX + 2 * xpad(2 * lane)) = hh;
@@ -705,7 +706,7 @@ __global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_fuse
               fir_pair<kDec1Taps, 1, 5, 18, 6>(xw, pidx, cf0, kCoDec1, o1[0], o1[1]);
             }
             {
-              float4 hh = make_float4(0, 0, 0, 0);
+              float4 hh = any_float4();
               if (lane < 14) hh = lds4(lds + kX + 2 * xpad(512 + 2 * lane));
               wave_sync();
               if (lane < 14) *reinterpret_cast<float4 *>(lds + kX + 2 * xpad(2 * lane)) = hh;
@@ -718,7 +719,7 @@ __global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_fuse
             fir_pair<kDec2Taps, 3, 5, 26, 6>(lds + kY1 + 4 * lane, planes, cf0, kCoDec2, ynew[sg][rd][0], ynew[sg][rd][1]);
           }
           {
-            float4 hh = make_float4(0, 0, 0, 0);
+            float4 hh = any_float4();
             if (lane < 24) hh = lds4(lds + kY1 + y1slot(128 + lane));
             wave_sync();
             if (lane < 24) *reinterpret_cast<float4 *>(lds + kY1 + y1slot(lane)) = hh;
@@ -875,6 +876,7 @@ __global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_fuse
           w[4 * i + 2] = t.z;
           w[4 * i + 3] = t.w;
         }
+        asm volatile("" ::"v"(w[0]));  // (rx512_kernel.hpp: or the 16-byte reads are narrowed to ds_read2_b32 + address adds)
 #pragma unroll
         for (int u = 0; u < 4; ++u) u1[h][u] = splat(0.0f);
 #pragma unroll
@@ -905,11 +907,15 @@ __global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_fuse
         const int sg = wv + NWV * h;
         float w[15];
         const float x1v[8] = {u1[h][0].x, u1[h][0].y, u1[h][1].x, u1[h][1].y, u1[h][2].x, u1[h][2].y, u1[h][3].x, u1[h][3].y};
+        // (the segment's eight history words as two 16-byte reads; [0] is padding and is kept alive on purpose --
+        // rx512_kernel.hpp, x2 window: without it the reads are narrowed to ds_read2_b32 at one address register each)
+        const float4 ya = lds4(YT + 8 * sg), yb = lds4(YT + 8 * sg + 4);
+        asm volatile("" ::"v"(ya.x));
+        const float hsv[8] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w};
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
           const float up = lane_up1(x1v[i + 1]);
-          const float hs = YT[8 * sg + i + 1];
-          w[i] = (lane == 0) ? hs : up;
+          w[i] = (lane == 0) ? hsv[i + 1] : up;
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) w[7 + i] = x1v[i];

@@ -1543,7 +1543,11 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
       for (int i = 0; i < 7; ++i) {
         const float up = lane_up1(x1[i + 1]);
         const float hs = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hist2), i + 1));
+  #if T41RX_WRITELANE  // (one v_writelane_b32 instead of the move + select `lane == 0 ? hs : up` compiles to)
+        w[i] = write_lane<0>(up, hs);
+  #else
         w[i] = (lane == 0) ? hs : up;
+  #endif
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) w[7 + i] = x1[i];
@@ -1564,11 +1568,17 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
         }
       }
       if (PART == 2 || KEEP) {  // the same seven values, kept for the next segment / frame: lane i = entry i
+  #if T41RX_WRITELANE  // (instead of move + compare + select per entry)
+  #define T41RX_HIST2_ENTRY(i) hist2c = write_lane<i>(hist2c, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x1[i]), 63)));
+        T41RX_HIST2_ENTRY(1) T41RX_HIST2_ENTRY(2) T41RX_HIST2_ENTRY(3) T41RX_HIST2_ENTRY(4) T41RX_HIST2_ENTRY(5) T41RX_HIST2_ENTRY(6) T41RX_HIST2_ENTRY(7)
+  #undef T41RX_HIST2_ENTRY
+  #else
 #pragma unroll
         for (int i = 1; i < 8; ++i) {
           const float t = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x1[i]), 63));
           hist2c = (lane == i) ? t : hist2c;
         }
+  #endif
       }
       // out[4n + j - 1] = sum_t state[n + t] * c[(4 - j) + 4 t],  state[n + t] = w[u + t]:
       // (out[4n], out[4n+1]) += w * (c[4t+3], c[4t+2]);  (out[4n+2], out[4n+3]) += w * (c[4t+1], c[4t])

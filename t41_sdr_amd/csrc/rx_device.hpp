@@ -53,6 +53,10 @@
 #include "rx_kernels.hpp"
 #include "wave_fft.hpp"
 
+// T41RX_WRITELANE=0: a scalar goes into one lane of a register by move + compare + select (A/B builds)
+#ifndef T41RX_WRITELANE
+#define T41RX_WRITELANE 1
+#endif
 // T41RX_SCAN_DPP=0: the DC high-pass scan's steps inside the rows as moves + packed multiply-adds (A/B builds)
 #ifndef T41RX_SCAN_DPP
 #define T41RX_SCAN_DPP 1
@@ -347,6 +351,14 @@ __device__ __forceinline__ float dc_highpass_end_state(const float (&x)[n], floa
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(B.x), 63));
 }
 
+// `old` with lane K replaced by the wave-uniform `s`: one v_writelane_b32 (this hipcc has no builtin for it and compiles
+// `lane == K ? s : old` to a move, a compare and a select).  No wait states needed around it: the lane select is an
+// immediate, and a VGPR it writes is read by plain VALU instructions only (no DPP / permlane reader right behind it).
+template <int K>
+__device__ __forceinline__ float write_lane(float old, float s) {
+  asm("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(s), "n"(K));
+  return old;
+}
 __device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
   const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
   const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));

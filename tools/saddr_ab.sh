@@ -7,11 +7,11 @@ export TMPDIR=/tmp
 timeout -k 10 600 python -m pytest tests -m gpu -x -q > gpurun_out/r05_pytest_saddr.log 2>&1
 rc=$?; echo "gpu tests rc $rc"; tail -n 3 gpurun_out/r05_pytest_saddr.log | cut -c1-200
 [ $rc = 0 ] || exit 3
-timeout -k 10 400 python tools/ab_probe.py product r5base noscan --rounds 3 --reps 60 > gpurun_out/r05_ab_saddr.txt 2>&1 || exit 3
+timeout -k 10 400 python tools/ab_probe.py product r5base nowl --rounds 3 --reps 60 > gpurun_out/r05_ab_saddr.txt 2>&1 || exit 3
 cat gpurun_out/r05_ab_saddr.txt
 : > gpurun_out/r05_ab_saddr_modes.txt
 for r in 1 2 3; do
-  for v in product r5base noscan; do
+  for v in product r5base; do
     if [ $v = product ]; then unset T41RX_LIB; else export T41RX_LIB=$PWD/t41_sdr_amd/abl/libt41rx_$v.so; fi
     for w in ${WORKLOADS:-fft4096 nfm am sam sam_agc ssb_agc ssb_agc_q15}; do
       T41RX_BENCH_NOCHECK=1 timeout -k 10 120 python bench.py --workload $w --steps 30 --warmup 8 --no-other-workloads --no-cpu-baseline 2>/dev/null | python -c "

@@ -25,11 +25,18 @@
 //    (G[k] + G[k-1]) / 2 -- which is what is applied here.  Per-bin statistics: two bins per lane.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "nr_kernels.hpp"
 #include "rx_kernels.hpp"
 #include "wave_fft.hpp"
 
 namespace t41 {
+
+// T41RX_NRSPEC_LDS_LOOP=1: the spectral function's bin loop as round 4 ran it, gains in LDS (A/B builds)
+#ifndef T41RX_NRSPEC_LDS_LOOP
+#define T41RX_NRSPEC_LDS_LOOP 0
+#endif
 
 // ------------------------------------------------------------------------------------------
 // Xanr(): 16 channels per wave, a channel's 64 taps on the four lanes (c, c + 16, c + 32, c + 48)
@@ -289,6 +296,28 @@ __device__ __forceinline__ float wave_sum(float v) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// the same sum, for its total only: six fused DPP additions (what wave_sum() compiles to spends three instructions on each
+// of the two row-stitching steps); same operands, same order
+__device__ __forceinline__ float wave_sum_fused(float v) {
+  asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 0"
+      : "+v"(v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ void lds_fence() { asm volatile("" ::: "memory"); }
+constexpr unsigned fbits(float x) { return __builtin_bit_cast(unsigned, x); }
+// is the (non-negative) power ratio with bit pattern rb within 5e-5 of one of the values NN changes at?  (Non-negative
+// floats order like their bit patterns; NaN patterns sit above every bound: "not near", and NN = 1 like the formula's.)
+__device__ __forceinline__ bool nr_ratio_near_edge(unsigned rb) {
+  bool near = false;
+  for (float b : {0.4f, 0.35f, 0.25f, 0.15f, 0.05f}) near = near || (rb >= fbits(b - 5e-5f) && rb <= fbits(b + 5e-5f));
+  return near;
+}
+
 template <int KIND>
 __global__ __launch_bounds__(64) void nrspec_kernel(const NrArgs a) {
 #pragma clang fp contract(off)
@@ -308,7 +337,9 @@ __global__ __launch_bounds__(64) void nrspec_kernel(const NrArgs a) {
   constexpr int KW = (KIND == 1) ? 128 : 1;  // (Kim1_NR()'s memories only)
   __shared__ float Xs[KIND == 1 ? 3 : 1][KW], Es[KIND == 1 ? 15 : 1][KW];  // Kim1_NR()'s frame histories
   __shared__ float Gts1[KW], Gts0[KW];
-  __shared__ float Gst[128], Lout[128], Nest[128], Pslp[128], Xt[128], Hk[128];
+  __shared__ float GstP[8 + 128 + 8];  // (padded: the smoothing windows of the edge bins reach 8 below / 4 above)
+  float *Gst = GstP + 8;
+  __shared__ float Lout[128], Nest[128], Pslp[128], Xt[128], Hk[128];
   const int lane = threadIdx.x;
   const int ch = blockIdx.x;
   if (ch >= a.nchan) return;
@@ -325,6 +356,10 @@ __global__ __launch_bounds__(64) void nrspec_kernel(const NrArgs a) {
   if (KIND == 1) {
     for (int i = lane; i < 3 * 128; i += 64) (&Xs[0][0])[i] = st[kNrX + i];
     for (int i = lane; i < 15 * 128; i += 64) (&Es[0][0])[i] = st[kNrE + i];
+  }
+  if (lane < 8) {
+    GstP[lane] = 0.0f;
+    GstP[8 + 128 + lane] = 0.0f;
   }
   for (int i = lane; i < 128; i += 64) {
     if (KIND == 1) {
@@ -507,6 +542,7 @@ __global__ __launch_bounds__(64) void nrspec_kernel(const NrArgs a) {
             if (i >= lo && i < hi) pre_part += X[k2][r];
           }
           const float pre_power = wave_sum(pre_part);
+#if T41RX_NRSPEC_LDS_LOOP
           for (int i = lo; i < hi; ++i) {  // Noise.cpp:529-588: the musical-noise treatment runs inside this loop
             if (lane == (i & 63)) {
               Gst[i] = (i >> 6) ? gnew[1] : gnew[0];
@@ -521,10 +557,6 @@ __global__ __launch_bounds__(64) void nrspec_kernel(const NrArgs a) {
             }
             const float post_power = wave_sum(post_part);
             float power_ratio = post_power / pre_power;
-            // The reference adds both sums up bin by bin in float (Noise.cpp:542-546); the tree sums above differ from
-            // that by rounding only, and all that is ever derived from the ratio is NN, which changes at 0.4, 0.35, 0.25,
-            // 0.15 and 0.05.  Next to one of those the sums are redone in the reference's order (every lane, the same
-            // values through LDS), so NN is decided exactly as the scalar code decides it.
             {
               bool near_edge = false;
 #pragma unroll
@@ -556,8 +588,6 @@ __global__ __launch_bounds__(64) void nrspec_kernel(const NrArgs a) {
               NN = 1 + 2 * (int)(0.5 + (double)NR_width * (1.0 - (double)(power_ratio / power_threshold)));
             }
             if (NN > 1) {
-              // centred average over NN bins; the reference's upper-edge pass (a backward average) overwrites the
-              // centred value of the last NN - NN/2 inner bins before the copy back (Noise.cpp:556-584)
               const int h = NN / 2;
               float nv[2] = {0.0f, 0.0f};
               bool mine[2] = {false, false};
@@ -582,6 +612,139 @@ __global__ __launch_bounds__(64) void nrspec_kernel(const NrArgs a) {
             }
             __syncthreads();
           }
+#else
+          // Round 5.  The loop is serial by construction (every pass sees the gains the previous pass's smoothing left)
+          // and the four waves of a SIMD keep its VALU busy: what a pass costs is its VALU instructions.  Round 4 kept
+          // the gains in LDS and spent ~140 of them per pass; this form spends ~40:
+          //  * the lane's two gains live in registers (Gr); bins 64..127 are left out of the loop when the pass band
+          //    ends below bin 64 (wave-uniform: it does for every filter up to 6 kHz);
+          //  * a pass that smooths publishes the gains once and requests its whole window in one go from a padded array
+          //    (no address clamps), the centred and the upper-edge average are summed from registers in the reference's
+          //    order, and s / NN is the correctly rounded quotient from a multiplication and two FMAs (NN is 3, 5, 7 or 9
+          //    and 1 / NN is correctly rounded: Markstein's theorem; checked on 64 M quotients per divisor);
+          //  * the power ratio only ever decides NN, which changes at 0.4, 0.35, 0.25, 0.15 and 0.05: away from those
+          //    (5e-5, bit patterns compared on the scalar unit) post_power x (1 / pre_power) decides, next to one of
+          //    them round 4's decision code runs as it was (true quotient, the reference's summation order), so NN is
+          //    decided exactly as before;
+          //  * the wave sum's six steps are six fused DPP additions.
+          // The same additions in the same order as the reference's loops: outputs and records are bit-identical to
+          // round 4's (tools/anr_ab_check.py).
+          float Gr[2] = {Gst[lane], Gst[64 + lane]};
+          const bool r1_live = hi > 64;
+          const bool in0 = lane >= lo && lane < hi, in1 = lane + 64 >= lo && lane + 64 < hi;
+          const float inv_pre = 1.0f / pre_power;
+          for (int i = lo; i < hi; ++i) {  // Noise.cpp:529-588: the musical-noise treatment runs inside this loop
+            {
+              const bool me = lane == (i & 63);
+              if (i >> 6) Gr[1] = me ? gnew[1] : Gr[1];
+              else Gr[0] = me ? gnew[0] : Gr[0];
+            }
+            float post_part = in0 ? Gr[0] * Gr[0] * X[k2][0] : 0.0f;
+            if (r1_live) post_part = in1 ? post_part + Gr[1] * Gr[1] * X[k2][1] : post_part;
+            const float post_power = wave_sum_fused(post_part);
+            int NN;
+            // (read into a scalar register by hand: through the builtin the compiler keeps the value in a VGPR and does
+            // the ten comparisons below on the VALU)
+            unsigned rb;
+            asm volatile("s_nop 0\n\tv_readfirstlane_b32 %0, %1" : "=s"(rb) : "v"(post_power * inv_pre));
+            if (!nr_ratio_near_edge(rb)) {
+              NN = rb > fbits(0.35f) ? 1 : rb > fbits(0.25f) ? 3 : rb > fbits(0.15f) ? 5 : rb > fbits(0.05f) ? 7 : 9;
+            } else {
+              float power_ratio = post_power / pre_power;
+              // The reference adds both sums up bin by bin in float (Noise.cpp:542-546); the tree sums above differ from
+              // that by rounding only.  Next to an edge the sums are redone in the reference's order (every lane, the same
+              // values through LDS), so NN is decided exactly as the scalar code decides it.
+              bool near_edge = false;
+#pragma unroll
+              for (float b : {0.4f, 0.35f, 0.25f, 0.15f, 0.05f}) near_edge = near_edge || fabsf(power_ratio - b) < 4e-5f;
+              if (near_edge) {
+                float *Pw = U + 640;  // (free between the transforms: the spectra occupy U[0 .. 520))
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                  const int j = lane + 64 * r;
+                  Pw[j] = X[k2][r];
+                  Pw[128 + j] = Gr[r] * Gr[r] * X[k2][r];
+                }
+                __syncthreads();
+                float pre_seq = 0.0f, post_seq = 0.0f;
+                for (int j = lo; j < hi; ++j) {
+                  pre_seq += Pw[j];
+                  post_seq += Pw[128 + j];
+                }
+                power_ratio = post_seq / pre_seq;
+                __syncthreads();
+              }
+              if (power_ratio > power_threshold) {
+                power_ratio = 1.0;
+                NN = 1;
+              } else {
+                NN = 1 + 2 * (int)(0.5 + (double)NR_width * (1.0 - (double)(power_ratio / power_threshold)));
+              }
+            }
+            if (NN > 1) {
+              // centred average over NN bins; the reference's upper-edge pass (a backward average) overwrites the
+              // centred value of the last NN - NN/2 inner bins before the copy back (Noise.cpp:556-584)
+              Gst[lane] = Gr[0];
+              if (r1_live) Gst[64 + lane] = Gr[1];
+              lds_fence();  // (one wave: its LDS operations execute in program order)
+              if (NN <= 9) {
+                auto smooth = [&](auto nn_tag) {
+                  constexpr int N = decltype(nn_tag)::value, H = N / 2;
+                  constexpr float rN = 1.0f / (float)N;
+#pragma unroll
+                  for (int r = 0; r < 2; ++r) {
+                    if (r == 1 && !r1_live) continue;
+                    const int j = lane + 64 * r;
+                    float g[N + H];  // g[t] = NR_G[j - N + 1 + t]
+#pragma unroll
+                    for (int t = 0; t < N + H; ++t) g[t] = Gst[j - N + 1 + t];
+                    float sc = 0.0, sb = 0.0;
+#pragma unroll
+                    for (int m = -H; m <= H; ++m) sc += g[N - 1 + m];     // m = j - h .. j + h
+#pragma unroll
+                    for (int m = 0; m > -N; --m) sb += g[N - 1 + m];      // m = j .. j - NN + 1
+                    const float sm = (j >= hi - N) ? sb : sc;
+                    const float q0 = sm * rN;
+                    const float nv = fmaf(fmaf(-q0, (float)N, sm), rN, q0);  // = sm / (float)N, correctly rounded
+                    if (j >= lo + H && j < hi - H) Gr[r] = nv;
+                  }
+                };
+                switch (NN) {
+                  case 3: smooth(std::integral_constant<int, 3>{}); break;
+                  case 5: smooth(std::integral_constant<int, 5>{}); break;
+                  case 7: smooth(std::integral_constant<int, 7>{}); break;
+                  default: smooth(std::integral_constant<int, 9>{}); break;
+                }
+              } else {  // (not reachable with NR_width = 4 and a ratio >= 0; kept as the reference's loops)
+                Gst[64 + lane] = Gr[1];
+                lds_fence();
+                const int h = NN / 2;
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                  const int j = lane + 64 * r;
+                  if (j >= lo + h && j < hi - h) {
+                    float sm = 0.0;
+                    if (j >= hi - NN) {
+                      for (int m = j; m > j - NN; --m) sm += Gst[m];
+                    } else {
+                      for (int m = j - h; m <= j + h; ++m) sm += Gst[m];
+                    }
+                    Gr[r] = sm / (float)NN;
+                  }
+                }
+              }
+              lds_fence();
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            const int i = lane + 64 * r;
+            Gst[i] = Gr[r];
+            if (i >= lo && i < hi) Hk[i] = hknew[r];
+          }
+          __syncthreads();
+#endif
 #pragma unroll
           for (int r = 0; r < 2; ++r) G[r] = Gst[lane + 64 * r] * 1.0f;  // x NR_long_tone_gain (1.0, Noise.cpp:706)
         }

@@ -455,7 +455,7 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
           }
         }
         f2 dcs = splat(0.0f);
-        dc_highpass<8>(z, dcs, lane, hp8.x, hp8.y);  // from rest: 512 samples on, its memory of the start is a1^512
+        dc_highpass<8, !AGC && MODE != kModeSam>(z, dcs, lane, hp8.x, hp8.y);  // from rest: 512 samples on, its memory of the start is a1^512
         if (!PLAIN) {
   #pragma unroll
           for (int k = 0; k < 8; ++k) {
@@ -535,7 +535,7 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
           }
         }
         const float x[4] = {tailF.x * g_rf, tailF.y * g_rf, tailF.z * g_rf, tailF.w * g_rf};
-        dc2 = f2{(g_rf_i != g_rf) ? -dc_carry : dc_carry, dc_highpass_end_state<4>(x, hp4.x, hp4.y)};
+        dc2 = f2{(g_rf_i != g_rf) ? -dc_carry : dc_carry, dc_highpass_end_state<4, !AGC && MODE != kModeSam>(x, hp4.x, hp4.y)};
       } else if (preroll) {
         dc2 = dc_pre;  // inside a frame both chains simply run on
       }
@@ -645,7 +645,7 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
           }
           STAMP(s == 0 ? 14 : 0);  // wait for the sub-block's global loads + gain/interleave (14: first sub-block)
         // -- DC high-pass (127-128), band gain (133-134) / IQ amplitude (166)
-          if (!T41RX_CUT(6)) dc_highpass<8>(z, dc2, lane, hp8.x, hp8.y);
+          if (!T41RX_CUT(6)) dc_highpass<8, !AGC && MODE != kModeSam>(z, dc2, lane, hp8.x, hp8.y);
           if (!PLAIN) {
             // band gain / IQ amplitude (Process.cpp:133-134, 166) and IQ phase correction
             // (Utility.cpp:178-187: phi < 0 mixes I into Q, phi > 0 mixes Q into I), branch-free:

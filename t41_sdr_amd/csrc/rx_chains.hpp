@@ -658,6 +658,38 @@ __device__ __forceinline__ void agc_chain(float *sl, CoefPtr cf0, int lane STAMP
   *reinterpret_cast<int4 *>(sl + kAgS + 4) = make_int4(st.state, st.decay_type, st.hang_counter, 0);
 }
 
+// max of the 23 group maxima p[0 .. 22] (the look-ahead window's whole groups).  As a loop `C = fmaxf(C, p[q])` hipcc
+// requests them one pair at a time -- ds_read2_b32, wait, maximum, next: twelve LDS round trips in a row, each with a VALU
+// addition for an address that does not fit ds_read2's offset field (round 5, ISA of the AGC kernels).  Here the base is
+// opaque (so the offsets are small), the requests go out in two batches and the maxima are taken three at a time.
+// (fmaxf: the result does not depend on the order.)
+__device__ __forceinline__ float agc_group_max(const float *p) {
+#if T41RX_AGC_GROUPMAX
+  typedef const __attribute__((address_space(3))) float *LdsFloats;  // (kept an LDS pointer: a laundered generic one is read by flat loads)
+  LdsFloats lp = (LdsFloats)p;
+  asm volatile("" : "+v"(lp));
+  float x[12], y[11];
+#pragma unroll
+  for (int q = 0; q < 12; ++q) x[q] = lp[q];
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int q = 0; q < 11; ++q) y[q] = lp[12 + q];
+  asm volatile("" ::: "memory");
+  float m = fmaxf(fmaxf(x[0], x[1]), x[2]);
+#pragma unroll
+  for (int q = 3; q + 1 < 12; q += 2) m = fmaxf(fmaxf(m, x[q]), x[q + 1]);
+  m = fmaxf(m, x[11]);
+#pragma unroll
+  for (int q = 0; q + 1 < 11; q += 2) m = fmaxf(fmaxf(m, y[q]), y[q + 1]);
+  return fmaxf(m, y[10]);
+#else
+  float C = p[0];
+#pragma unroll
+  for (int q = 1; q <= 22; ++q) C = fmaxf(C, p[q]);
+  return C;
+#endif
+}
+
 // v[4 + j] = inverse FFT output sample i = lane + 64 j (the valid half); agst = this lane's
 // float4 of the channel's AGC record (lanes 0..49 delay line, 50..51 state words).
 // og[k] = AGC output sample 4 lane + k.
@@ -694,9 +726,7 @@ __device__ __forceinline__ void agc_apply(const cf (&v)[8], float4 agst, float *
     const float4 nv = lds4(lds + kAgA + 100 + 4 * lane);
     const float4 g1 = lds4(lds + kAgA + 4 + 4 * lane);
     const float ao0 = lds[kAgA + 3 + 4 * lane];
-    float C = lds[kAgG + lane + 2];
-#pragma unroll
-    for (int q = 3; q <= 24; ++q) C = fmaxf(C, lds[kAgG + lane + q]);
+    const float C = agc_group_max(lds + kAgG + lane + 2);
     const float s3 = g1.w, s2 = fmaxf(g1.z, s3), s1 = fmaxf(g1.y, s2), s0 = fmaxf(g1.x, s1);
     const float p0 = nv.x, p1 = fmaxf(p0, nv.y), p2 = fmaxf(p1, nv.z), p3 = fmaxf(p2, nv.w);
     *reinterpret_cast<float4 *>(lds + kAgR + 4 * lane) =
@@ -872,9 +902,7 @@ __device__ __forceinline__ float4 agc_prep_pipe(const cf (&v)[8], float4 agst, f
     const float4 nv = lds4(lds + kAgA + 100 + 4 * lane);
     const float4 g1 = lds4(lds + kAgA + 4 + 4 * lane);
     const float ao0 = lds[kAgA + 3 + 4 * lane];
-    float C = lds[kAgG + lane + 2];
-#pragma unroll
-    for (int q = 3; q <= 24; ++q) C = fmaxf(C, lds[kAgG + lane + q]);
+    const float C = agc_group_max(lds + kAgG + lane + 2);
     const float s3 = g1.w, s2 = fmaxf(g1.z, s3), s1 = fmaxf(g1.y, s2), s0 = fmaxf(g1.x, s1);
     const float p0 = nv.x, p1 = fmaxf(p0, nv.y), p2 = fmaxf(p1, nv.z), p3 = fmaxf(p2, nv.w);
     *reinterpret_cast<float4 *>(slot + 4 * lane) =

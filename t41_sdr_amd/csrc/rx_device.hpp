@@ -53,6 +53,11 @@
 #include "rx_kernels.hpp"
 #include "wave_fft.hpp"
 
+// T41RX_AGC_GROUPMAX=1: the look-ahead window's 23 group maxima requested in two batches instead of pair by pair
+// (round 5: twelve LDS round trips fewer per frame and no faster, profiles/r05_ab_saddr4_modes.txt; off)
+#ifndef T41RX_AGC_GROUPMAX
+#define T41RX_AGC_GROUPMAX 0
+#endif
 // T41RX_WRITELANE=0: a scalar goes into one lane of a register by move + compare + select (A/B builds)
 #ifndef T41RX_WRITELANE
 #define T41RX_WRITELANE 1
@@ -270,13 +275,14 @@ struct HpTab {
 // every lane: 4 row_shr steps inside each 16-lane row, then row_bcast:15 / row_bcast:31 to
 // stitch the rows.  m15 = A^((lane&15)+1), m31 = A^((lane&31)+1) (per-lane constants).
 // Works on an (I, Q) pair of chains at once.
-template <int n>
+template <int n, bool FUSED = true>
 __device__ __forceinline__ f2 hp_scan(f2 B, float m15, float m31) {
   constexpr HpTab<n> T{};
-#if T41RX_SCAN_DPP
-  // (round 5: the four steps inside the rows the same way -- two v_fmac_f32_dpp instead of two v_mov_b32_dpp and a
-  // packed multiply-add; the same fused operations on the same operands, so the same bits)
-  {
+  // (FUSED: four more VGPRs hold the steps' multipliers -- the AGC / SAM kernels, which sit at the 128-register limit,
+  // spill for it and keep the moves)
+  if (FUSED && T41RX_SCAN_DPP) {
+    // (round 5: the four steps inside the rows the same way -- two v_fmac_f32_dpp instead of two v_mov_b32_dpp and a
+    // packed multiply-add; the same fused operations on the same operands, so the same bits)
     float sx = B.x, sy = B.y;
     asm("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
         "v_fmac_f32_dpp %1, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
@@ -289,13 +295,12 @@ __device__ __forceinline__ f2 hp_scan(f2 B, float m15, float m31) {
         : "+v"(sx), "+v"(sy)
         : "v"(T.scanA[0]), "v"(T.scanA[1]), "v"(T.scanA[2]), "v"(T.scanA[3]));
     B = f2{sx, sy};
+  } else {
+    B = pk_fma(splat(T.scanA[0]), dpp_f2<kDppRowShr1, 0xf, true>(B), B);
+    B = pk_fma(splat(T.scanA[1]), dpp_f2<kDppRowShr2, 0xf, true>(B), B);
+    B = pk_fma(splat(T.scanA[2]), dpp_f2<kDppRowShr4, 0xf, true>(B), B);
+    B = pk_fma(splat(T.scanA[3]), dpp_f2<kDppRowShr8, 0xf, true>(B), B);
   }
-#else
-  B = pk_fma(splat(T.scanA[0]), dpp_f2<kDppRowShr1, 0xf, true>(B), B);
-  B = pk_fma(splat(T.scanA[1]), dpp_f2<kDppRowShr2, 0xf, true>(B), B);
-  B = pk_fma(splat(T.scanA[2]), dpp_f2<kDppRowShr4, 0xf, true>(B), B);
-  B = pk_fma(splat(T.scanA[3]), dpp_f2<kDppRowShr8, 0xf, true>(B), B);
-#endif
   // the two row-stitching steps as v_fmac_f32 with the DPP operand built in (VOP2; the packed
   // form needs the shuffled value in a register first, zeroed for the rows the step leaves alone):
   // rows outside row_mask are simply not written
@@ -321,7 +326,7 @@ __device__ __forceinline__ f2 hp_scan(f2 B, float m15, float m31) {
 // instead of three (b0 x and b1 x each round once here; the reference rounds b0 x inside the sum:
 // a difference of one ulp of x, far inside the path's tolerance).
 static_assert(kHpB1 == -kHpB0, "the pre-scaled form of the DC high-pass needs b1 = -b0");
-template <int n>
+template <int n, bool FUSED = true>
 __device__ __forceinline__ void dc_highpass(f2 (&x)[n], f2 &carry, int lane, float m15, float m31) {
   constexpr HpTab<n> T{};
   const float a1 = (float)kHpA1;
@@ -332,7 +337,7 @@ __device__ __forceinline__ void dc_highpass(f2 (&x)[n], f2 &carry, int lane, flo
     d = pk_fma(splat(a1), y, -x[k]);
     x[k] = y;
   }
-  const f2 B = hp_scan<n>(d, m15, m31);
+  const f2 B = hp_scan<n, FUSED>(d, m15, m31);
   const f2 e = f2{lane_up1(B.x), lane_up1(B.y)};
 #pragma unroll
   for (int k = 0; k < n; ++k) x[k] = pk_fma(splat(T.pw[k]), e, x[k]);
@@ -341,13 +346,13 @@ __device__ __forceinline__ void dc_highpass(f2 (&x)[n], f2 &carry, int lane, flo
 }
 
 // filter state after `n` samples per lane when only the end state matters (zero start state)
-template <int n>
+template <int n, bool FUSED = true>
 __device__ __forceinline__ float dc_highpass_end_state(const float (&x)[n], float m15, float m31) {
   const float c = (float)(kHpB1 + kHpA1 * kHpB0), a1 = (float)kHpA1;
   float d = 0.0f;
 #pragma unroll
   for (int k = 0; k < n; ++k) d = fmaf(a1, d, c * x[k]);
-  const f2 B = hp_scan<n>(f2{d, 0.0f}, m15, m31);
+  const f2 B = hp_scan<n, FUSED>(f2{d, 0.0f}, m15, m31);
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(B.x), 63));
 }
 

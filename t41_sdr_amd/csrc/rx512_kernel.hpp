@@ -177,6 +177,8 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
   const double raw_r = ncs_rd->r;
   const float raw_dc = st[kStMisc + kMiscDc];
   uint64_t dphi = 0, phase0 = 0;
+  constexpr bool kKeepPl = T41RX_PHASE_SPLIT && T41RX_KEEP_PL && KEEP && !AGC && MODE != kModeSam;
+  uint64_t pl_keep = 0;  // (8 lane + 1) dphi, the lane's part of the oscillator phases of a frame
   double osc_r = 1.0;
   float dc_carry = 0.0f;
   bool transient = false;
@@ -426,6 +428,11 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
       STAMP(18);  // prologue c: delay lines -> LDS
       if (first_iter) {
         dphi = uniform_u64(raw_dphi);
+        if (kKeepPl) {
+          unsigned n1 = (unsigned)(8 * lane + 1);
+          asm volatile("" : "+v"(n1));  // (or the product is if-converted out of this block and worked out on every frame again)
+          pl_keep = (uint64_t)n1 * dphi;
+        }
         phase0 = uniform_u64(raw_phase) + (uint64_t)f * (uint64_t)L * dphi;  // (f = 0 unless SEGPAR: closed form)
         osc_r = uniform_f64(raw_r);
         dc_carry = uniform_f32(raw_dc);
@@ -554,7 +561,9 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
       float2 osc_tab[4];
       uint32_t osc_u[4];
       {
-        const uint64_t Pl = (uint64_t)(unsigned)(8 * lane + 1) * dphi;
+        // (the lane's part does not change from frame to frame: where registers are to spare it is worked out once --
+        // two 64-bit multiply-adds and two 32-bit multiplies, quarter-rate instructions, per frame otherwise)
+        const uint64_t Pl = kKeepPl ? pl_keep : (uint64_t)(unsigned)(8 * lane + 1) * dphi;
   #pragma unroll
         for (int sb = 0; sb < 4; ++sb) {
   #if T41RX_PHASE_SPLIT

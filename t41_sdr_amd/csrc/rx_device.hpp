@@ -58,6 +58,10 @@
 #ifndef T41RX_AGC_GROUPMAX
 #define T41RX_AGC_GROUPMAX 0
 #endif
+// T41RX_KEEP_PL=0: the lane's part of the oscillator phases worked out per frame (A/B builds)
+#ifndef T41RX_KEEP_PL
+#define T41RX_KEEP_PL 1
+#endif
 // T41RX_WRITELANE=0: a scalar goes into one lane of a register by move + compare + select (A/B builds)
 #ifndef T41RX_WRITELANE
 #define T41RX_WRITELANE 1

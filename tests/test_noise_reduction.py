@@ -251,6 +251,10 @@ NR_CASES = {
     # function's conditioning (it divides by small noise estimates), not the kernel's arithmetic
     "spectral": (dict(nrOptionSelect=2), 5e-5, "most"),
     "spectral-am-agc": (dict(nrOptionSelect=2, mode=2, FLoCut=-3000, FHiCut=3000, AGCMode=2), 2e-5, "most"),
+    # round 5: a pass band that ends above bin 64 of the stage's 128 (9 kHz / 93.75 Hz = 96): the bin loop then runs over
+    # both of a lane's bins and the smoothing windows cross from one register set to the other (with the 3 kHz filters of
+    # the other cases the kernel leaves bins 64..127 out of the loop altogether)
+    "spectral-wide": (dict(nrOptionSelect=2, FLoCut=200, FHiCut=9000), 5e-5, "most"),
 }
 
 
@@ -484,3 +488,47 @@ def test_gpu_live_switch_spectral_to_kim_matches_the_oracle(built):
     ref = ob.process(I[:, 8 * L:], Q[:, 8 * L:])
     e = siggen.block_rel_err(got, ref, L)
     assert e.max() <= 1e-4, e.max(axis=0)  # Kim's tolerance (its conditioning), from the first frame after the switch
+
+
+def test_smoothing_width_by_thresholds_equals_the_reference_formula_away_from_its_edges():
+    """nr_kernels.hip (round 5) decides NN from the bit pattern of post_power * (1 / pre_power) by five comparisons when the
+    ratio is farther than 5e-5 from 0.4 / 0.35 / 0.25 / 0.15 / 0.05, and runs the reference's expression (Noise.cpp:547-552,
+    on the true quotient) only next to those.  Here: (a) on a dense sweep of float32 ratios outside the guard bands the
+    comparisons give the formula's NN, also for a ratio that is off by the few ulp a reciprocal multiplication can be;
+    (b) the guard bands, compared as unsigned bit patterns, contain every ratio the old float test |r - b| < 4e-5 catches."""
+    f32 = np.float32
+    edges = np.array([0.4, 0.35, 0.25, 0.15, 0.05], dtype=f32)
+
+    def formula(r):
+        r = r.astype(f32)
+        q = (r / f32(0.4)).astype(f32).astype(np.float64)
+        nn = 1 + 2 * np.floor(0.5 + 4.0 * (1.0 - q)).astype(np.int64)   # (int) of a non-negative double
+        return np.where(r > f32(0.4), 1, nn)
+
+    def by_thresholds(r):
+        b = r.astype(f32).view(np.uint32)
+        t = lambda x: np.array([x], dtype=f32).view(np.uint32)[0]
+        return np.where(b > t(0.35), 1, np.where(b > t(0.25), 3, np.where(b > t(0.15), 5, np.where(b > t(0.05), 7, 9))))
+
+    def near_bits(r):
+        b = r.astype(f32).view(np.uint32)
+        out = np.zeros(r.shape, dtype=bool)
+        for e in edges:
+            lo = np.array([e - f32(5e-5)], dtype=f32).view(np.uint32)[0]
+            hi = np.array([e + f32(5e-5)], dtype=f32).view(np.uint32)[0]
+            out |= (b >= lo) & (b <= hi)
+        return out
+
+    rng = np.random.default_rng(3)
+    r = np.concatenate([np.linspace(0.0, 1.2, 2_000_001), rng.uniform(0.0, 0.45, 2_000_000),
+                        (edges[:, None].astype(np.float64) + np.linspace(-2e-4, 2e-4, 20001)[None, :]).ravel()]).astype(f32)
+    far = ~near_bits(r)
+    assert far.mean() > 0.9
+    assert (by_thresholds(r[far]) == formula(r[far])).all()
+    for ulps in (-3, -1, 1, 3):  # the reciprocal form's ratio, a few ulp off the quotient's
+        off = (r.view(np.uint32).astype(np.int64) + ulps).clip(0).astype(np.uint32).view(f32)
+        assert (by_thresholds(off[far]) == formula(r[far])).all()
+    old_near = np.zeros(r.shape, dtype=bool)
+    for e in edges:
+        old_near |= np.abs(r - e) < f32(4e-5)
+    assert not (old_near & far).any()

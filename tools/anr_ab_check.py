@@ -20,6 +20,7 @@ out = {}
 for name, kw, nch, nfr in [("notch", dict(ANR_notchOn=1), 37, 9), ("lms+notch", dict(nrOptionSelect=3, ANR_notchOn=1), 16, 6),
                            ("lms", dict(nrOptionSelect=3), 50, 5), ("notch-am-agc", dict(ANR_notchOn=1, mode=2, FLoCut=-3000, FHiCut=3000, AGCMode=2), 33, 8),
                            ("kim", dict(nrOptionSelect=1), 21, 12), ("spectral", dict(nrOptionSelect=2), 40, 40),
+                           ("spectral-wide", dict(nrOptionSelect=2, FLoCut=200, FHiCut=9000), 24, 30),
                            ("spectral-am-agc-notch", dict(nrOptionSelect=2, ANR_notchOn=1, mode=2, FLoCut=-3000, FHiCut=3000, AGCMode=3), 17, 30)]:
     p = dict(mode=0, FLoCut=200, FHiCut=3000); p.update(kw)
     nco = siggen.nco_grid(nch, seed=7)

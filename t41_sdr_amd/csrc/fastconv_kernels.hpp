@@ -423,6 +423,11 @@ __global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_kern
 // scratch per lane that stay in L2) measures 51.4-51.6 against 53.1-53.3 us per frame interleaved on one box, and the fabric
 // traffic falls from 1.153 to 1.077 x the algorithmic bytes (the 16 KiB round trip through the record is gone):
 // profiles/r05_ab_prevreg.txt.  (Round 3, 85 spilled SGPRs, two sub-blocks in flight: 56.4 against 54.2 the other way.)
+// T41RX_FF_REGTAIL=1: the /4 decimator's window tail from registers here too (rx512_kernel.hpp; measured: 49.78 against
+// 49.68 us per frame and one more spilled register, HBM traffic 1.075 -> 1.082 x: off)
+#ifndef T41RX_FF_REGTAIL
+#define T41RX_FF_REGTAIL 0
+#endif
 #ifndef T41RX_FF_PREV_GLOBAL
 #define T41RX_FF_PREV_GLOBAL 0  // 1: the "previous" block waits in the channel's record (L2) instead of 16 registers per lane
 #endif
@@ -703,7 +708,8 @@ __global__ __launch_bounds__((64 * kFcWaves), T41RX_FC_WAVES) void fastconv_fuse
             cf o1[2];
             {
               auto pidx = [](int o) { return xpad(o); };
-              fir_pair<kDec1Taps, 1, 5, 18, 6>(xw, pidx, cf0, kCoDec1, o1[0], o1[1]);
+              if (T41RX_DEC1_REGTAIL && T41RX_FF_REGTAIL) fir_pair<kDec1Taps, 1, 5, 18, 6, 14>(xw, pidx, cf0, kCoDec1, o1[0], o1[1], nullptr, z);  // (rx512_kernel.hpp)
+              else fir_pair<kDec1Taps, 1, 5, 18, 6>(xw, pidx, cf0, kCoDec1, o1[0], o1[1]);
             }
             {
               float4 hh = any_float4();

@@ -756,7 +756,10 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
             } else if (!T41RX_CUT(4)) {
               // (round 4, measured and dropped: the window requested one group ahead of its use behind scheduling
               //  barriers, taps in 16-tap scalar loads -- 18 spilled registers, 26.7 against 22.4 us per frame)
-              fir_pair<kDec1Taps, 1, 5, 18, 6>(xw, pidx, cf0, kCoDec1, o1[0], o1[1]);
+              // (round 5: window entries 28.. are the lane's own new samples, still in z: three of the 17 reads come from
+              // there -- where registers are to spare)
+              if (T41RX_DEC1_REGTAIL && !AGC && MODE != kModeSam) fir_pair<kDec1Taps, 1, 5, 18, 6, 14>(xw, pidx, cf0, kCoDec1, o1[0], o1[1], nullptr, z);
+              else fir_pair<kDec1Taps, 1, 5, 18, 6>(xw, pidx, cf0, kCoDec1, o1[0], o1[1]);
             } else {
               o1[0] = *reinterpret_cast<cf *>(xw);
               o1[1] = *reinterpret_cast<cf *>(xw + 8);

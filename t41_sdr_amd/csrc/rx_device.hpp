@@ -62,6 +62,10 @@
 #ifndef T41RX_KEEP_PL
 #define T41RX_KEEP_PL 1
 #endif
+// T41RX_DEC1_REGTAIL=0: the /4 decimator reads its whole window from LDS, the lane's own eight samples included (A/B builds)
+#ifndef T41RX_DEC1_REGTAIL
+#define T41RX_DEC1_REGTAIL 1
+#endif
 // T41RX_WRITELANE=0: a scalar goes into one lane of a register by move + compare + select (A/B builds)
 #ifndef T41RX_WRITELANE
 #define T41RX_WRITELANE 1
@@ -630,8 +634,11 @@ __device__ __forceinline__ cf fir_mac(float tap, cf x, cf acc) {
 }
 // (T41RX_LOO 13 / 14, timing experiments: the /2 / the /4 decimator's window taken from registers `regsrc` instead of
 // LDS -- the arithmetic kept, the LDS reads gone: what would a decimator that needs no window reads be worth?)
-template <int NT, int OFF0, int OFF1, int NLOAD, int GROUP, typename IDX>
-__device__ __forceinline__ void fir_pair(const float *win, IDX idx, CoefPtr coef, int taps, cf &acc0, cf &acc1, const cf *regsrc = nullptr) {
+// (TAIL0, `tail`: round 5 -- the window's loads from TAIL0 on are the lane's OWN newest samples, which it still holds in
+// registers: taken from there, the same values, and the LDS reads are not issued)
+template <int NT, int OFF0, int OFF1, int NLOAD, int GROUP, int TAIL0 = 1 << 20, typename IDX>
+__device__ __forceinline__ void fir_pair(const float *win, IDX idx, CoefPtr coef, int taps, cf &acc0, cf &acc1, const cf *regsrc = nullptr,
+                                         const cf *tail = nullptr) {
   constexpr int NTP = (NT + 7) & ~7;
   float tc[NTP];
   acc0 = splat(0.0f);
@@ -641,6 +648,7 @@ __device__ __forceinline__ void fir_pair(const float *win, IDX idx, CoefPtr coef
     if (l > 0 && (l % GROUP) == 0) asm volatile("" : "+v"(acc0), "+v"(acc1)::"memory");
     float4 t;
     if (regsrc) t = make_float4(regsrc[(2 * l) & 7].x, regsrc[(2 * l) & 7].y, regsrc[(2 * l + 1) & 7].x, regsrc[(2 * l + 1) & 7].y);
+    else if (tail && l >= TAIL0) t = make_float4(tail[2 * (l - TAIL0)].x, tail[2 * (l - TAIL0)].y, tail[2 * (l - TAIL0) + 1].x, tail[2 * (l - TAIL0) + 1].y);
     else t = lds4(win + 2 * idx(2 * l));
     const cf tv[2] = {cf{t.x, t.y}, cf{t.z, t.w}};
 #pragma unroll

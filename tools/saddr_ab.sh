@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 timeout -k 10 600 python -m pytest tests -m gpu -x -q > gpurun_out/r05_pytest_saddr.log 2>&1
 rc=$?; echo "gpu tests rc $rc"; tail -n 3 gpurun_out/r05_pytest_saddr.log | cut -c1-200
 [ $rc = 0 ] || exit 3
-timeout -k 10 400 python tools/ab_probe.py product r5base --rounds 3 --reps 60 > gpurun_out/r05_ab_saddr.txt 2>&1 || exit 3
+timeout -k 10 400 python tools/ab_probe.py product noregtail r5base --rounds 4 --reps 60 > gpurun_out/r05_ab_saddr.txt 2>&1 || exit 3
 cat gpurun_out/r05_ab_saddr.txt
 : > gpurun_out/r05_ab_saddr_modes.txt
 for r in 1 2 3; do

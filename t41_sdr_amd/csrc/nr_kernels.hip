@@ -33,6 +33,10 @@
 
 namespace t41 {
 
+// T41RX_ANR_PREFETCH=0: the notch's window requested at the top of its own sample step, as in round 4 (A/B builds)
+#ifndef T41RX_ANR_PREFETCH
+#define T41RX_ANR_PREFETCH 1
+#endif
 // T41RX_NRSPEC_LDS_LOOP=1: the spectral function's bin loop as round 4 ran it, gains in LDS (A/B builds)
 #ifndef T41RX_NRSPEC_LDS_LOOP
 #define T41RX_NRSPEC_LDS_LOOP 0
@@ -115,6 +119,77 @@ __device__ __forceinline__ void anr_pass_y(const float *T, float *O, const float
   // holds): tap pair t is updated, then used.  Same values as updating all taps first.
   float c0 = 1.0f, c1 = 0.0f;  // pending update of the previous sample (none yet: w * 1 + 0 * d would not be exact for
   bool pending = false;        // -0 / NaN taps, so it is skipped rather than applied)
+#if T41RX_ANR_PREFETCH
+  // Round 5: a sample's window is requested at the top of the PREVIOUS sample's step, into a third register set -- the
+  // delay line is the input signal, so every window of the frame is in the tile before the pass starts.  Requested at
+  // the top of its own step, as in round 4, the window is waited for twice per sample (two batches of eight reads) at the
+  // head of the dependent sequence.  (Requested behind the products into the previous window's registers -- two sets --
+  // the chain's first sixteen additions no longer interleave with the products: 148 against 140 us per frame.)
+  // (ONE lane-dependent base, opaque to the compiler, and the sixteen rows at immediate offsets from it: eight
+  // ds_read2_b32 -- the pairs are 17 dwords apart, 15 x 17 = 255 just fits the offset field.  Left to itself hipcc keeps
+  // eight address registers, adds the sample's offset to each and issues sixteen single reads: 25 instructions for 9.)
+  typedef const __attribute__((address_space(3))) float *LdsRow;
+  LdsRow wbase = (LdsRow)(T + c + (kAnrTaps - 16 - tb) * kAnrRow);
+  asm volatile("" : "+v"(wbase));
+  auto window = [&](int i, f2 (&dj)[8], float &d_in) {
+    d_in = T[i * kAnrRow + c + kAnrHist * kAnrRow];  // ANR_d[ANR_in_idx]
+    LdsRow row = wbase + i * kAnrRow;
+#pragma unroll
+    for (int t = 0; t < 16; t += 2)
+      dj[t / 2] = f2{row[(14 - t) * kAnrRow], row[(15 - t) * kAnrRow]};
+  };
+  // dj: this sample's window (in registers); dp: the previous sample's, for the pending update; dx: takes the next one's
+  auto step = [&](int i, const f2 (&dj)[8], const f2 (&dp)[8], f2 (&dx)[8], const float d_in, float &d_next) {
+    if (i + 1 < 256) window(i + 1, dx, d_next);
+    // (wave 1 runs a sample ahead: this sample's sigma, with what depends on sigma alone, has been in its slot since the
+    // previous sample's barrier)
+    const float4 sg = *reinterpret_cast<const float4 *>(SIG + 4 * (kAnrCw * (i & 1) + c));
+    __builtin_amdgcn_sched_barrier(0);  // (the requests go out HERE: left alone, the scheduler sinks them behind the chain)
+    f2 p[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      if (pending) w[t] = splat(c0) * w[t] + splat(c1) * dp[t];
+      p[t] = w[t] * dj[t];
+    }
+    const float y = anr_from_group2(anr_chain(p));
+    __syncthreads();  // keeps wave 1 exactly one sample ahead (it must not overwrite a slot this wave has yet to read)
+    const float sigma = sg.x, inv_sigp = sg.y;  // inv_sigp = (float)(1.0 / ((double)sigma + 1e-10))
+    const double one_m = __hiloint2double(__float_as_int(sg.w), __float_as_int(sg.z));  // 1.0 - (double)(ANR_two_mu * sigma * inv_sigp)
+    const float error = d_in - y;
+    if (O && g == 0) O[i * kAnrRow + c] = NOTCH ? error : y;
+    float nel = (float)((double)error * one_m);
+    if (nel < 0.0f) nel = -nel;
+    float nev = (float)((double)d_in - (1.0 - (double)(ANR_two_mu * ngamma)) * (double)y - (double)(ANR_two_mu * error * sigma * inv_sigp));
+    if (nev < 0.0f) nev = -nev;
+    if (nev < nel) {  // as written (Noise.cpp:351-356): the else-if belongs to the inner if
+      lidx += ANR_lincr;
+      if (lidx > ANR_lidx_max) {
+        lidx = ANR_lidx_max;
+      } else {
+        lidx -= ANR_ldecr;
+        if (lidx < ANR_lidx_min) lidx = ANR_lidx_min;
+      }
+    }
+    ngamma = ANR_gamma * (lidx * lidx) * (lidx * lidx) * ANR_den_mult;
+    c0 = (float)(1.0 - (double)(ANR_two_mu * ngamma));
+    c1 = ANR_two_mu * error * inv_sigp;
+    pending = true;
+  };
+  f2 da[8], db[8], dc[8];
+  float din_a, din_b = 0.0f, din_c = 0.0f;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) dc[t] = splat(0.0f);
+  window(0, da, din_a);
+  __syncthreads();  // wave 1's sigma of sample 0
+  for (int i = 0; i < 255; i += 3) {  // 85 x 3 samples
+    step(i, da, dc, db, din_a, din_b);      // window i in da, i - 1 in dc; i + 1 -> db
+    step(i + 1, db, da, dc, din_b, din_c);  // i + 2 -> dc
+    step(i + 2, dc, db, da, din_c, din_a);  // i + 3 -> da
+  }
+  step(255, da, dc, db, din_a, din_b);
+#pragma unroll
+  for (int t = 0; t < 8; ++t) db[t] = da[t];  // the last sample's update below takes its window from db
+#else
   auto step = [&](int i, f2 (&dj)[8], const f2 (&dp)[8]) {
     const float *row = T + i * kAnrRow + c;
     const float d_in = row[kAnrHist * kAnrRow];  // ANR_d[ANR_in_idx]
@@ -162,6 +237,7 @@ __device__ __forceinline__ void anr_pass_y(const float *T, float *O, const float
     step(i, da, db);
     step(i + 1, db, da);
   }
+#endif
   // the last sample's update (its window is in db)
 #pragma unroll
   for (int t = 0; t < 8; ++t) w[t] = splat(c0) * w[t] + splat(c1) * db[t];
@@ -169,7 +245,7 @@ __device__ __forceinline__ void anr_pass_y(const float *T, float *O, const float
 __device__ __forceinline__ void anr_pass_sigma(const float *T, float *SIG, int lane) {
 #pragma clang fp contract(off)
   const int c = lane & 15, g = lane >> 4, tb = anr_tap_base(g);
-  for (int i = 0; i < 256; ++i) {
+  auto sigma_of = [&](int i) {
     const float *row = T + i * kAnrRow + c;
     f2 q[8];
 #pragma unroll
@@ -184,8 +260,23 @@ __device__ __forceinline__ void anr_pass_sigma(const float *T, float *SIG, int l
     if (g == 2)
       *reinterpret_cast<float4 *>(SIG + 4 * (kAnrCw * (i & 1) + c)) =
           make_float4(sigma, inv_sigp, __int_as_float(__double2loint(one_m)), __int_as_float(__double2hiint(one_m)));
+  };
+#if T41RX_ANR_PREFETCH
+  // one sample AHEAD of the filter wave: sigma of sample i is in its slot before the barrier of sample i - 1, so the filter
+  // wave reads it at the top of its step, not behind its chain (the slot it overwrites, i + 1's = i - 1's, was read at the
+  // top of step i - 1, a barrier ago)
+  sigma_of(0);
+  __syncthreads();
+  for (int i = 0; i < 256; ++i) {
+    if (i + 1 < 256) sigma_of(i + 1);
     __syncthreads();
   }
+#else
+  for (int i = 0; i < 256; ++i) {
+    sigma_of(i);
+    __syncthreads();
+  }
+#endif
 }
 
 __global__ __launch_bounds__(128, 2) void anr_kernel(const NrArgs a) {

@@ -58,7 +58,7 @@ constexpr int kAnrCw = 16;                     // channels per wave / workgroup
 constexpr int kAnrRow = kAnrCw + 1;            // LDS row pitch in floats (odd: the transposing stage-in / stage-out and the window reads are conflict-free)
 constexpr int kAnrTile = kAnrHist + 256;       // rows of the input tile: 79 of history + the frame
 constexpr int kAnrSigOff = ((kAnrTile + 256) * kAnrRow + 3) & ~3;
-constexpr size_t kAnrLdsBytes = ((size_t)kAnrSigOff + 2 * kAnrCw * 4) * sizeof(float);  // input tile + output tile + two slots of 16 x (sigma, 1 / sigma', 1 - 2 mu sigma / sigma' as a double)
+constexpr size_t kAnrLdsBytes = ((size_t)kAnrSigOff + 3 * kAnrCw * 4) * sizeof(float);  // input tile + output tile + three (round 4: two) slots of 16 x (sigma, 1 / sigma', 1 - 2 mu sigma / sigma' as a double)
 
 // first tap of lane group g: the chain visits the groups in the order 0, 1, 3, 2
 __device__ __forceinline__ int anr_tap_base(int g) { return 16 * ((g == 2) ? 3 : (g == 3) ? 2 : g); }
@@ -139,11 +139,11 @@ __device__ __forceinline__ void anr_pass_y(const float *T, float *O, const float
       dj[t / 2] = f2{row[(14 - t) * kAnrRow], row[(15 - t) * kAnrRow]};
   };
   // dj: this sample's window (in registers); dp: the previous sample's, for the pending update; dx: takes the next one's
-  auto step = [&](int i, const f2 (&dj)[8], const f2 (&dp)[8], f2 (&dx)[8], const float d_in, float &d_next) {
+  auto step = [&](int i, int slot, const f2 (&dj)[8], const f2 (&dp)[8], f2 (&dx)[8], const float d_in, float &d_next) {
     if (i + 1 < 256) window(i + 1, dx, d_next);
     // (wave 1 runs a sample ahead: this sample's sigma, with what depends on sigma alone, has been in its slot since the
     // previous sample's barrier)
-    const float4 sg = *reinterpret_cast<const float4 *>(SIG + 4 * (kAnrCw * (i & 1) + c));
+    const float4 sg = *reinterpret_cast<const float4 *>(SIG + 4 * (kAnrCw * slot + c));  // (slot = i % 3: static per unrolled step)
     __builtin_amdgcn_sched_barrier(0);  // (the requests go out HERE: left alone, the scheduler sinks them behind the chain)
     f2 p[8];
 #pragma unroll
@@ -157,11 +157,13 @@ __device__ __forceinline__ void anr_pass_y(const float *T, float *O, const float
     const double one_m = __hiloint2double(__float_as_int(sg.w), __float_as_int(sg.z));  // 1.0 - (double)(ANR_two_mu * sigma * inv_sigp)
     const float error = d_in - y;
     if (O && g == 0) O[i * kAnrRow + c] = NOTCH ? error : y;
-    float nel = (float)((double)error * one_m);
-    if (nel < 0.0f) nel = -nel;
-    float nev = (float)((double)d_in - (1.0 - (double)(ANR_two_mu * ngamma)) * (double)y - (double)(ANR_two_mu * error * sigma * inv_sigp));
-    if (nev < 0.0f) nev = -nev;
-    if (nev < nel) {  // as written (Noise.cpp:351-356): the else-if belongs to the inner if
+    // |nel|, |nev|: the reference's `if (x < 0) x = -x` and fabsf() differ for x = -0 only, and the two are only ever
+    // compared with each other; as operand modifiers of that comparison they cost nothing (as written hipcc compares the
+    // DOUBLES with zero and selects: two half-rate compares and two selects per sample)
+    const float nel = fabsf((float)((double)error * one_m));
+    const float nev = fabsf((float)((double)d_in - (1.0 - (double)(ANR_two_mu * ngamma)) * (double)y - (double)(ANR_two_mu * error * sigma * inv_sigp)));
+    if (nev < nel) {  // as written (Noise.cpp:351-356): the else-if belongs to the inner if.  (Branches on purpose: most samples
+      // skip the block; the same logic as selects is seven instructions on every sample and measured 2 us per frame slower)
       lidx += ANR_lincr;
       if (lidx > ANR_lidx_max) {
         lidx = ANR_lidx_max;
@@ -182,11 +184,11 @@ __device__ __forceinline__ void anr_pass_y(const float *T, float *O, const float
   window(0, da, din_a);
   __syncthreads();  // wave 1's sigma of sample 0
   for (int i = 0; i < 255; i += 3) {  // 85 x 3 samples
-    step(i, da, dc, db, din_a, din_b);      // window i in da, i - 1 in dc; i + 1 -> db
-    step(i + 1, db, da, dc, din_b, din_c);  // i + 2 -> dc
-    step(i + 2, dc, db, da, din_c, din_a);  // i + 3 -> da
+    step(i, 0, da, dc, db, din_a, din_b);      // window i in da, i - 1 in dc; i + 1 -> db
+    step(i + 1, 1, db, da, dc, din_b, din_c);  // i + 2 -> dc
+    step(i + 2, 2, dc, db, da, din_c, din_a);  // i + 3 -> da
   }
-  step(255, da, dc, db, din_a, din_b);
+  step(255, 0, da, dc, db, din_a, din_b);  // (255 = 3 x 85)
 #pragma unroll
   for (int t = 0; t < 8; ++t) db[t] = da[t];  // the last sample's update below takes its window from db
 #else
@@ -258,7 +260,7 @@ __device__ __forceinline__ void anr_pass_sigma(const float *T, float *SIG, int l
     const float inv_sigp = (float)(1.0 / ((double)sigma + 1e-10));
     const double one_m = 1.0 - (double)(ANR_two_mu * sigma * inv_sigp);
     if (g == 2)
-      *reinterpret_cast<float4 *>(SIG + 4 * (kAnrCw * (i & 1) + c)) =
+      *reinterpret_cast<float4 *>(SIG + 4 * (kAnrCw * (T41RX_ANR_PREFETCH ? i % 3 : (i & 1)) + c)) =
           make_float4(sigma, inv_sigp, __int_as_float(__double2loint(one_m)), __int_as_float(__double2hiint(one_m)));
   };
 #if T41RX_ANR_PREFETCH

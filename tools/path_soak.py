@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
-"""GPU box: soak of the noise-reduction / notch kernels of the product against another build of the library
+"""GPU box: soak of the receive path of the product against another build of the library
 (t41_sdr_amd/abl/libt41rx_NAME.so), bit for bit, on random shapes and parameters: each library runs the same seeded
 sequence of cases in its own process for SECONDS, the outputs' and checkpoints' hashes are compared case by case.
-Cases: nrOptionSelect 0..3 x ANR_notchOn, filters from 2.4 to 9.5 kHz wide (above 6 kHz the spectral function's bin loop
-runs over both of a lane's bins), USB / LSB / AM, AGC off or on, 1..70 channels, two calls of 1..12 frames.
-usage: python tools/nr_soak.py NAME [SECONDS]"""
+Cases: USB / LSB / AM / NFM (both discriminators) / SAM, AGCMode 0..4, unit and non-unit gains with and without the IQ
+correction (the PLAIN and the general kernels), FFT_LENGTH 512 / 1024 / 2048 / 4096, 1..300 channels, two calls of 1..40
+frames (short calls take the barrier forms, long ones the pipelined ones).  Round 5: the product against the build with
+every same-result switch of rx_device.hpp set back (abl/libt41rx_r5base.so).
+usage: python tools/path_soak.py NAME [SECONDS]"""
 import json
 import os
 import subprocess
@@ -21,21 +23,24 @@ budget, ncases = %f, %d
 rng = np.random.default_rng(20261005)
 out, t0 = [], time.time()
 for case in range(ncases):
-    nr = int(rng.integers(0, 4)); notch = int(rng.integers(0, 2))
-    if nr == 0 and notch == 0: notch = 1
-    width = int(rng.choice([2400, 2800, 3000, 4000, 5500, 6500, 8000, 9500]))
-    mode = int(rng.choice([0, 1, 2]))
-    lo, hi = (200, 200 + width) if mode == 0 else ((-200 - width, -200) if mode == 1 else (-width // 2 - 1500, width // 2 + 1500))
-    if mode == 2: lo, hi = -min(width, 5000), min(width, 5000)
-    kw = dict(mode=mode, FLoCut=lo, FHiCut=hi, nrOptionSelect=nr, ANR_notchOn=notch, AGCMode=int(rng.choice([0, 0, 1, 3])))
-    nch, n1, n2 = int(rng.integers(1, 71)), int(rng.integers(1, 13)), int(rng.integers(1, 13))
+    mode = int(rng.choice([0, 1, 2, 3, 8]))
+    fft = int(rng.choice([512, 512, 512, 1024, 2048, 4096]))
+    if mode == 0: lo, hi = 200, int(rng.choice([2400, 3000, 4000]))
+    elif mode == 1: lo, hi = -int(rng.choice([2400, 3000, 4000])), -200
+    else: lo, hi = -int(rng.choice([3000, 5000])), int(rng.choice([3000, 5000]))
+    kw = dict(mode=mode, FLoCut=lo, FHiCut=hi, fft_length=fft, AGCMode=int(rng.integers(0, 5)))
+    if mode == 3: kw["nfm_demod"] = int(rng.integers(0, 2))
+    if rng.integers(0, 2):
+        kw.update(RFgain=int(rng.choice([-6, 3, 10])), IQAmpCorrectionFactor=float(rng.choice([1.0, 1.04, 0.97])), IQPhaseCorrectionFactor=float(rng.choice([0.0, 0.02, -0.03])))
+    seg = kw['fft_length'] // 512
+    nch, n1, n2 = int(rng.choice([1, 2, 3, 5, 15, 16, 17, 31, 33, 64, 100, 255, 300])), seg * int(rng.integers(1, 41 // seg + 1)), seg * int(rng.integers(1, 41 // seg + 1))
     seed = int(rng.integers(1 << 30))
     if time.time() - t0 > budget:
         break
     try:
         p = T.default_params(**kw)
         nco = siggen.nco_grid(nch, seed=seed & 0xffff)
-        I, Q = siggen.make_iq(nch, (n1 + n2) * 2048, nco, mode=mode, seed=seed)
+        I, Q = siggen.make_iq(nch, (n1 + n2) * 2048, nco, mode=(2 if mode == 8 else mode), seed=seed)
         rx = T.RxChain(nch, p, NCOFreq=nco)
         h = hashlib.sha256()
         for sl in (slice(0, n1 * 2048), slice(n1 * 2048, (n1 + n2) * 2048)):

@@ -5,7 +5,7 @@
 # copies the summaries into profiles/ and rewrites profiles/hbm_traffic.json.
 # usage: tools/profile_round.sh TAG [workload ...]
 TAG=$1; shift
-WL=${@:-ssb ssb_time_major ssb_1fpl ssb_4fpl nfm nfm_atan am sam sam_agc ssb_agc ssb_q15 ssb_agc_q15 fft4096 ssb_notch ssb_kim ssb_spectral}
+WL=${@:-ssb ssb_32fpl ssb_time_major ssb_1fpl ssb_4fpl nfm nfm_atan am sam sam_agc ssb_agc ssb_q15 ssb_agc_q15 fft4096 ssb_notch ssb_kim ssb_spectral}
 export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT="$ROOT/gpurun_out/profile_$TAG"

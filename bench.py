@@ -469,8 +469,10 @@ def main():
         others = {}
         for name in OTHER_WORKLOADS:
             w = Workload(torch, T, name, 1, 0, local_rank, dev, None, 0)
-            # >= 384 frames of every channel in the timed region: 12 launches of 32 frames, 96 of 4, 384 of 1
-            wsteps, wwarm = max(12, 384 // w.frames), 4
+            # >= 1280 frames of every channel in the timed region: 40 launches of 32 frames, 320 of 4, 1280 of 1 (until the end
+            # of round 5: 12 / 96 / 384 launches behind 4 of warm-up -- 8 ms of timed region for the fast workloads, most of it
+            # inside the clock's ramp: those entries read 2-3 % below the same workload's 30-launch A/B runs)
+            wsteps, wwarm = max(40, 1280 // w.frames), 8
             _, kms = w.time(wsteps, wwarm)
             r = w.roofline(kms)
             entry = {"workload": w.wl["name"], "batch": w.n, "frames_per_launch": w.frames, "steps": wsteps, "warmup": wwarm,

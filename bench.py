@@ -63,19 +63,19 @@ WORKLOADS = {
     "am": dict(batch=4096, fft=512, kw=dict(mode=2, FLoCut=-3000, FHiCut=3000),
                name="AM path (AlphaBetaMag envelope, DC block, biquad low-pass; Process.cpp:697-707), 4096 channels x 2048 "
                     "samples per frame"),
-    "sam": dict(batch=4096, fft=512, kw=dict(mode=8, FLoCut=-3000, FHiCut=3000),
+    "sam": dict(batch=4096, fft=512, kw=dict(mode=8, FLoCut=-3000, FHiCut=3000), frames=128,
                 name="synchronous AM (AMDecodeSAM, Demod.cpp:40-139: a per-sample PLL, serial in time; SURVEY 8f rank 4), "
                      "4096 channels x 2048 samples per frame"),
-    "sam_agc": dict(batch=4096, fft=512, kw=dict(mode=8, FLoCut=-3000, FHiCut=3000, AGCMode=1),
+    "sam_agc": dict(batch=4096, fft=512, kw=dict(mode=8, FLoCut=-3000, FHiCut=3000, AGCMode=1), frames=128,
                     name="synchronous AM behind the firmware's default AGCMode = 1 (Demod.cpp:40-139 behind DSP_Fn.cpp:504-631): two serial "
                          "chains per frame, each on a duty wave of its own (round 4), 4096 channels x 2048 samples per frame"),
-    "ssb_agc": dict(batch=4096, fft=512, kw=dict(mode=0, FLoCut=200, FHiCut=3000, AGCMode=1),
+    "ssb_agc": dict(batch=4096, fft=512, kw=dict(mode=0, FLoCut=200, FHiCut=3000, AGCMode=1), frames=128,
                     name="configs[1] with the firmware's default AGCMode = 1 (look-ahead AGC, DSP_Fn.cpp:504-631) instead of "
                          "the fixed gain: 4096 channels x 2048 samples per frame (SURVEY 8f rank 1)"),
     "ssb_q15": dict(batch=4096, fft=512, kw=dict(mode=0, FLoCut=200, FHiCut=3000), q15=True,
                     name="configs[1] on the firmware's own sample format either side (q15 record-queue blocks in, "
                          "arm_float_to_q15 out; Process.cpp:102-111, 936): 6 B per input complex sample (SURVEY 8f rank 3)"),
-    "ssb_agc_q15": dict(batch=4096, fft=512, kw=dict(mode=0, FLoCut=200, FHiCut=3000, AGCMode=1), q15=True,
+    "ssb_agc_q15": dict(batch=4096, fft=512, kw=dict(mode=0, FLoCut=200, FHiCut=3000, AGCMode=1), q15=True, frames=128,
                         name="configs[1] exactly as the firmware ships: AGCMode = 1 (gwv.cpp:15) and q15 samples either side "
                              "(Process.cpp:102-111, 936): 6 B per input complex sample"),
     "ssb_notch": dict(batch=4096, fft=512, kw=dict(mode=0, FLoCut=200, FHiCut=3000, ANR_notchOn=1), frames=32,
@@ -90,7 +90,7 @@ WORKLOADS = {
                           "channel per call, as ShowSpectrum() calls it (Display.cpp:339) -- streaming state through HBM every call"),
     "ssb_4fpl": dict(batch=4096, fft=512, kw=dict(mode=0, FLoCut=200, FHiCut=3000), frames=4,
                      name="configs[1] with 4 frames (42.7 ms of signal) buffered per call"),
-    "fft4096": dict(batch=1024, fft=4096, kw=dict(mode=0, FLoCut=400, FHiCut=600), frames=32,
+    "fft4096": dict(batch=1024, fft=4096, kw=dict(mode=0, FLoCut=400, FHiCut=600), frames=64,
                     name="configs[3]: PSK31-like narrow USB filter, 4096-pt fast-conv (synthetic generalisation), "
                          "1024 channels x 16384 samples per frame"),
 }
@@ -103,6 +103,9 @@ KERNEL_SOURCES = tuple("t41_sdr_amd/csrc/" + f for f in (
     "rx_long.hip", "fastconv.hip", "rx_dispatch.hip", "nr_kernels.hip", "nr_kernels.hpp"))
 # what the default run times behind the headline (N = 1): every mode and sample format the README claims, each replayed
 # against the oracle, and the headline workload in the firmware's own calling shape (1 frame per call) and at 4 frames
+# (frames per launch: 128 for the headline and for the workloads whose serial chains run as a pipeline across the frames of a
+# launch -- AGC on, SAM: the pipeline's fill and drain are per launch --, 64 long frames for configs[3], 32 for the rest;
+# profiles/r05_fpl_sweep2.txt, r05_fpl_sweep_others.txt)
 OTHER_WORKLOADS = ("ssb_32fpl", "nfm", "nfm_atan", "am", "sam", "fft4096", "ssb_agc", "ssb_q15", "ssb_agc_q15", "sam_agc", "ssb_time_major",
                    "ssb_1fpl", "ssb_4fpl", "ssb_kim", "ssb_spectral", "ssb_notch")
 

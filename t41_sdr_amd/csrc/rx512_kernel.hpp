@@ -177,7 +177,7 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
   const double raw_r = ncs_rd->r;
   const float raw_dc = st[kStMisc + kMiscDc];
   uint64_t dphi = 0, phase0 = 0;
-  constexpr bool kKeepPl = T41RX_PHASE_SPLIT && T41RX_KEEP_PL && KEEP && !AGC && MODE != kModeSam;
+  constexpr bool kKeepPl = T41RX_PHASE_SPLIT && T41RX_KEEP_PL && KEEP && !AGC && (MODE != kModeSam || T41RX_SAM_KEEP_PL);
   uint64_t pl_keep = 0;  // (8 lane + 1) dphi, the lane's part of the oscillator phases of a frame
   double osc_r = 1.0;
   float dc_carry = 0.0f;
@@ -462,7 +462,7 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
           }
         }
         f2 dcs = splat(0.0f);
-        dc_highpass<8, !AGC && MODE != kModeSam>(z, dcs, lane, hp8.x, hp8.y);  // from rest: 512 samples on, its memory of the start is a1^512
+        dc_highpass<8, !AGC && (MODE != kModeSam || T41RX_SAM_SCAN_FUSED)>(z, dcs, lane, hp8.x, hp8.y);  // from rest: 512 samples on, its memory of the start is a1^512
         if (!PLAIN) {
   #pragma unroll
           for (int k = 0; k < 8; ++k) {
@@ -542,7 +542,7 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
           }
         }
         const float x[4] = {tailF.x * g_rf, tailF.y * g_rf, tailF.z * g_rf, tailF.w * g_rf};
-        dc2 = f2{(g_rf_i != g_rf) ? -dc_carry : dc_carry, dc_highpass_end_state<4, !AGC && MODE != kModeSam>(x, hp4.x, hp4.y)};
+        dc2 = f2{(g_rf_i != g_rf) ? -dc_carry : dc_carry, dc_highpass_end_state<4, !AGC && (MODE != kModeSam || T41RX_SAM_SCAN_FUSED)>(x, hp4.x, hp4.y)};
       } else if (preroll) {
         dc2 = dc_pre;  // inside a frame both chains simply run on
       }
@@ -654,7 +654,7 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
           }
           STAMP(s == 0 ? 14 : 0);  // wait for the sub-block's global loads + gain/interleave (14: first sub-block)
         // -- DC high-pass (127-128), band gain (133-134) / IQ amplitude (166)
-          if (!T41RX_CUT(6)) dc_highpass<8, !AGC && MODE != kModeSam>(z, dc2, lane, hp8.x, hp8.y);
+          if (!T41RX_CUT(6)) dc_highpass<8, !AGC && (MODE != kModeSam || T41RX_SAM_SCAN_FUSED)>(z, dc2, lane, hp8.x, hp8.y);
           if (!PLAIN) {
             // band gain / IQ amplitude (Process.cpp:133-134, 166) and IQ phase correction
             // (Utility.cpp:178-187: phi < 0 mixes I into Q, phi > 0 mixes Q into I), branch-free:
@@ -757,8 +757,9 @@ __global__ __launch_bounds__((Geo<PART, geo4(MODE, AGC) && !PIPE>::kWaves * 64),
               // (round 4, measured and dropped: the window requested one group ahead of its use behind scheduling
               //  barriers, taps in 16-tap scalar loads -- 18 spilled registers, 26.7 against 22.4 us per frame)
               // (round 5: window entries 28.. are the lane's own new samples, still in z: three of the 17 reads come from
-              // there -- where registers are to spare)
-              if (T41RX_DEC1_REGTAIL && !AGC && MODE != kModeSam) fir_pair<kDec1Taps, 1, 5, 18, 6, 14>(xw, pidx, cf0, kCoDec1, o1[0], o1[1], nullptr, z);
+              // there -- in the kernels without the AGC (with it: neutral for SSB, 1 % slower behind SAM; SAM alone gains 2.8 %
+              // although it spills two registers for it, profiles/r05_ab_regtail_agc.txt))
+              if (T41RX_DEC1_REGTAIL && (!AGC || T41RX_DEC1_REGTAIL_AGC)) fir_pair<kDec1Taps, 1, 5, 18, 6, 14>(xw, pidx, cf0, kCoDec1, o1[0], o1[1], nullptr, z);
               else fir_pair<kDec1Taps, 1, 5, 18, 6>(xw, pidx, cf0, kCoDec1, o1[0], o1[1]);
             } else {
               o1[0] = *reinterpret_cast<cf *>(xw);

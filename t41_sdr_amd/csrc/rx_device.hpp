@@ -66,6 +66,18 @@
 #ifndef T41RX_DEC1_REGTAIL
 #define T41RX_DEC1_REGTAIL 1
 #endif
+// T41RX_DEC1_REGTAIL_AGC=1: the same in the kernels with the AGC (measured: neutral to 1 % slower)
+#ifndef T41RX_DEC1_REGTAIL_AGC
+#define T41RX_DEC1_REGTAIL_AGC 0
+#endif
+// T41RX_SAM_SCAN_FUSED / T41RX_SAM_KEEP_PL = 1: the fused scan steps / the kept phase product in the SAM kernel (without the AGC) too
+// (measured: 56.1 -> 56.9 -> 58.7 us per frame with one, with both: the registers cost more than the instructions save)
+#ifndef T41RX_SAM_SCAN_FUSED
+#define T41RX_SAM_SCAN_FUSED 0
+#endif
+#ifndef T41RX_SAM_KEEP_PL
+#define T41RX_SAM_KEEP_PL 0
+#endif
 // T41RX_WRITELANE=0: a scalar goes into one lane of a register by move + compare + select (A/B builds)
 #ifndef T41RX_WRITELANE
 #define T41RX_WRITELANE 1

@@ -44,7 +44,8 @@ WORKLOADS = {
     # 128 frames per launch since the end of round 5 (rounds 1-4 and most of round 5: 32, still timed as `ssb_32fpl`): the
     # previous review asked for the sweep and "if it pays, make it the default and say so in config"; on the round's final
     # kernels it pays 0.5-0.9 % (profiles/r05_fpl_sweep2.txt: 20.83 / 20.60 us per frame at 32, 20.67 / 20.68 at 64,
-    # 20.52 / 20.53 at 128 on one box).  A channel's filter memories stay on chip for the whole call either way.
+    # 20.52 / 20.53 at 128 on one box) in 100-launch runs and 2-4 % in the 25 launches of `--steps 20 --warmup 5`, where 32-frame
+    # launches spend their 13 ms inside the clock's ramp.  A channel's filter memories stay on chip for the whole call either way.
     "ssb": dict(batch=4096, fft=512, kw=dict(mode=0, FLoCut=200, FHiCut=3000), frames=128,
                 name="configs[1]: batched SSB (USB 200-3000 Hz) RX chain, decimate-by-8 + 512-pt fast-conv + demod + "
                      "interpolate-by-8, 4096 channels x 2048 complex f32 samples per frame per GPU, per-channel NCO, AGC off, "
